@@ -1,0 +1,127 @@
+"""Generates tests/golden/*.npz by IMPORTING the reference's own Python modules on CPU.
+
+Run only in the build container (needs /root/reference); the fixtures it writes are data
+(inputs + expected outputs) and are committed, the reference itself never travels.
+
+    python oracle/make_golden.py [--ref /root/reference] [--out tests/golden]
+
+Modules used (SURVEY.md 8c "importable here"):
+  utils.sh_utils        eval_sh, RGB2SH, SH2RGB                       -> sh_eval.npz
+  utils.general_utils   build_rotation, build_scaling_rotation,
+                        strip_symmetric  (torch.zeros/device shim)     -> cov3d.npz
+  utils.graphics_utils  getWorld2View2, getProjectionMatrix,
+                        focal2fov, fov2focal, geom_transform_points    -> camera.npz, geom_transform.npz
+  utils.loss_utils      l1_loss, ssim ; utils.image_utils psnr         -> loss.npz
+The rasterizer itself (diff_gaussian_rasterization) is absent from the reference, so there
+is no fixture for the boundary: "parity unpinned" (see oracle/gsr_ref.c).
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden"))
+    a = ap.parse_args()
+    sys.path.insert(0, a.ref)
+    os.makedirs(a.out, exist_ok=True)
+    torch.manual_seed(0)
+    rng = np.random.default_rng(0)
+
+    # ---- SH ----
+    from utils import sh_utils
+    dirs = rng.normal(size=(64, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    sh = rng.normal(0, 0.4, size=(64, 3, 16))          # reference layout for eval_sh: [..., C, coeffs]
+    out = {}
+    for deg in range(4):
+        r = sh_utils.eval_sh(deg, torch.tensor(sh), torch.tensor(dirs)).numpy()
+        out[f"rgb_raw_deg{deg}"] = r
+        out[f"rgb_clamped_deg{deg}"] = torch.clamp_min(torch.tensor(r) + 0.5, 0.0).numpy()   # gaussian_renderer/__init__.py:78
+    rgb = rng.uniform(0, 1, size=(16, 3))
+    np.savez(os.path.join(a.out, "sh_eval.npz"), dirs=dirs, sh_view=sh, rgb=rgb,
+             rgb2sh=sh_utils.RGB2SH(rgb), sh2rgb=sh_utils.SH2RGB(rgb), C0=sh_utils.C0, C1=sh_utils.C1,
+             C2=np.array(sh_utils.C2), C3=np.array(sh_utils.C3), **out)
+
+    # ---- cov3D (device="cuda" is hard-wired in the reference: shim torch.zeros) ----
+    from utils import general_utils
+    _zeros = torch.zeros
+
+    def zeros_cpu(*args, **kw):
+        kw.pop("device", None)
+        return _zeros(*args, **kw)
+    torch.zeros = zeros_cpu
+    try:
+        s = np.exp(rng.normal(-2.0, 0.7, size=(64, 3))).astype(np.float32)
+        q = rng.normal(size=(64, 4)).astype(np.float32)            # un-normalised on purpose
+        qn = q / np.linalg.norm(q, axis=1, keepdims=True)
+        res = {}
+        for mod in (1.0, 0.5):
+            L = general_utils.build_scaling_rotation(torch.tensor(mod * s), torch.tensor(q))
+            cov = L @ L.transpose(1, 2)
+            res[f"cov6_mod{mod}"] = general_utils.strip_symmetric(cov).numpy()
+        Rm = general_utils.build_rotation(torch.tensor(q)).numpy()
+    finally:
+        torch.zeros = _zeros
+    np.savez(os.path.join(a.out, "cov3d.npz"), scales=s, quats_raw=q, quats_unit=qn.astype(np.float32), rot=Rm, **res)
+
+    # ---- camera matrices ----
+    from utils import graphics_utils as gu
+    cams = {}
+    intr = {"table": (3049.779011853469, 4032, 2268), "tiramisu": (3287.4641158882314, 4032, 2268)}
+    for name, (f, w, h) in intr.items():
+        fx, fy = gu.focal2fov(f, w), gu.focal2fov(f, h)
+        cams[f"{name}_fovx"] = fx; cams[f"{name}_fovy"] = fy
+        cams[f"{name}_focal_back"] = gu.fov2focal(fx, w)
+        cams[f"{name}_proj"] = gu.getProjectionMatrix(0.01, 100.0, fx, fy).numpy()
+    poses_R, poses_T, w2v, wvt, full, center = [], [], [], [], [], []
+    fovx, fovy = cams["table_fovx"], cams["table_fovy"]
+    for i in range(4):
+        A = rng.normal(size=(3, 3)); Q, _ = np.linalg.qr(A)
+        if np.linalg.det(Q) < 0: Q[:, 0] = -Q[:, 0]
+        T = rng.normal(size=3) * 2.0
+        trans = np.array([0.1 * i, -0.2, 0.3]); scale = 1.0 + 0.25 * i
+        m = gu.getWorld2View2(Q, T, trans, scale)
+        # scene/cameras.py:54-57 on CPU
+        t_wvt = torch.tensor(m).transpose(0, 1)
+        t_proj = gu.getProjectionMatrix(znear=0.01, zfar=100.0, fovX=fovx, fovY=fovy).transpose(0, 1)
+        t_full = (t_wvt.unsqueeze(0).bmm(t_proj.unsqueeze(0))).squeeze(0)
+        t_center = t_wvt.inverse()[3, :3]
+        poses_R.append(Q); poses_T.append(T); w2v.append(m); wvt.append(t_wvt.numpy()); full.append(t_full.numpy()); center.append(t_center.numpy())
+    cams.update(R=np.array(poses_R), T=np.array(poses_T), translate=np.array([[0.1 * i, -0.2, 0.3] for i in range(4)]),
+                scale=np.array([1.0 + 0.25 * i for i in range(4)]), w2v=np.array(w2v), world_view_transform=np.array(wvt),
+                full_proj_transform=np.array(full), camera_center=np.array(center),
+                w2v_identity=gu.getWorld2View2(np.eye(3), np.array([0.0, 0.0, 3.0])))
+    np.savez(os.path.join(a.out, "camera.npz"), **cams)
+
+    # ---- geom_transform_points (the 1e-7 perspective epsilon) ----
+    # points placed in front of pose 0 (camera space x,y in +-1, z in 2..6, some behind), moved to world space
+    pc = np.stack([rng.uniform(-1, 1, 64), rng.uniform(-0.6, 0.6, 64), rng.uniform(2, 6, 64), np.ones(64)], 1)
+    pc[:8, 2] = rng.uniform(-3, 0.15, 8)
+    pts = (pc @ np.linalg.inv(wvt[0].astype(np.float64)))[:, :3].astype(np.float32)
+    gt = gu.geom_transform_points(torch.tensor(pts), torch.tensor(full[0])).numpy()
+    np.savez(os.path.join(a.out, "geom_transform.npz"), points=pts, matrix=full[0], out=gt)
+
+    # ---- loss ----
+    from utils import loss_utils, image_utils
+    img1 = torch.tensor(rng.uniform(0, 1, size=(3, 64, 64)).astype(np.float32), requires_grad=True)
+    img2 = torch.tensor(rng.uniform(0, 1, size=(3, 64, 64)).astype(np.float32))
+    l1 = loss_utils.l1_loss(img1, img2)
+    ss = loss_utils.ssim(img1, img2)
+    loss = (1.0 - 0.2) * l1 + 0.2 * (1.0 - ss)                       # train.py:91-92, lambda_dssim arguments/__init__.py:83
+    loss.backward()
+    ps = image_utils.psnr(img1.detach()[None], img2[None])
+    np.savez(os.path.join(a.out, "loss.npz"), img1=img1.detach().numpy(), img2=img2.numpy(), l1=l1.item(), ssim=ss.item(),
+             loss=loss.item(), grad=img1.grad.numpy(), psnr=ps.numpy())
+    print("wrote", sorted(os.listdir(a.out)))
+
+
+if __name__ == "__main__":
+    main()
