@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""bench.py -- forward+backward renders/sec of the HIP rasterizer on BASELINE.json's headline config.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3_synth_1M_1080p] [--no-cpu-baseline]
+
+A "step" is one forward + backward pass of the rasterizer (GaussianRasterizer through the
+C ABI) for one 1920x1080 camera over 1 M synthetic Gaussians already resident in HBM, with a
+fixed upstream gradient dL/dimage (the metric excludes loss and optimiser).
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank renders its own camera
+over the replicated Gaussians and the 59-float/Gaussian parameter-gradient bucket is summed with
+one RCCL all-reduce inside the step (weak scaling in cameras).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def algorithmic_bytes(P, N, HW, K, M):
+    """Per-stage algorithmic bytes of one render (SURVEY.md 8d / BASELINE.md 4): every stage reads
+    its inputs once and writes its outputs once; the sort counts one read + one write of the pairs."""
+    return {
+        "fwd.preprocess": (44 + 12 * K + 75) * P,
+        "fwd.scan": 8 * P,
+        "fwd.emit_keys": 20 * P + 12 * N,
+        "fwd.sort": 24 * N,
+        "fwd.ranges": 8 * N,
+        "fwd.composite": 40 * N + 20 * HW,
+        "bwd.zero_acc": 0,
+        "bwd.composite": 40 * N + 20 * HW + 36 * P,
+        "bwd.pergauss": (111 + 12 * K + 64 + 12 * M) * P,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg3_synth_1M_1080p")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from gaussian_transformer_amd import GaussianRasterizationSettings, GaussianRasterizer, synth
+    from gaussian_transformer_amd import _lib
+    from gaussian_transformer_amd.render import TorchCamera
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    sc = synth.make_config(args.config, seed=0)
+    cam_np = sc.camera
+    if world > 1:   # one camera per rank: same intrinsics, camera yawed by a rank-dependent angle about the cloud's centre
+        from gaussian_transformer_amd.camera import look_at_camera
+        ang = (rank - (world - 1) / 2.0) * math.radians(6.0)
+        centre = np.array([0.0, 0.0, 6.0])
+        eye = centre + 6.0 * np.array([math.sin(ang), 0.0, -math.cos(ang)])
+        cam_np = look_at_camera(eye, centre, (0.0, -1.0, 0.0), cam_np.FoVx, cam_np.image_width, cam_np.image_height)
+    cam = TorchCamera(cam_np, dev)
+    W, H, P = cam.image_width, cam.image_height, sc.P
+    D = sc.sh_degree
+    M = sc.shs.shape[1]
+    t = lambda a, g=False: torch.tensor(a, dtype=torch.float32, device=dev).requires_grad_(g)
+    means3D, opac, shs = t(sc.means3D, True), t(sc.opacities, True), t(sc.shs, True)
+    scales, rots = t(sc.scales, True), t(sc.rotations, True)
+    params = [means3D, opac, shs, scales, rots]
+    dL = t(sc.dL_dimage)
+    bg = t(sc.bg)
+    rs = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam_np.tanfovx, tanfovy=cam_np.tanfovy, bg=bg, scale_modifier=1.0,
+        viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=D,
+        campos=cam.camera_center, prefiltered=False, debug=False)
+    flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev) if world > 1 else None
+    state = {}
+
+    def step():
+        means2D = torch.zeros((P, 3), dtype=torch.float32, device=dev, requires_grad=True)
+        rast = GaussianRasterizer(raster_settings=rs)
+        color, radii = rast(means3D=means3D, means2D=means2D, shs=shs, opacities=opac, scales=scales, rotations=rots)
+        grads = torch.autograd.grad(color, params, grad_outputs=dL)
+        if world > 1:
+            off = 0
+            for g in grads:
+                flat[off:off + g.numel()].copy_(g.reshape(-1)); off += g.numel()
+            dist.all_reduce(flat)
+        state["color"], state["grads"] = color, grads
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.steps / dt
+
+    # ---- second pass over the same K steps with per-stage hipEvents on the launch stream ----
+    lib = _lib.load()
+    import ctypes as C
+    lib.gsr_set_profiling(1)
+    names = (C.c_char_p * _lib.GSR_NUM_STAGES)()
+    ms = (C.c_float * _lib.GSR_NUM_STAGES)()
+    acc = np.zeros(_lib.GSR_NUM_STAGES)
+    nprof = max(1, min(args.steps, 10))
+    for _ in range(nprof):
+        step()
+        lib.gsr_get_stage_times(names, ms)
+        acc += np.array(list(ms))
+    lib.gsr_set_profiling(0)
+    stage_ms = {names[i].decode(): float(acc[i] / nprof) for i in range(_lib.GSR_NUM_STAGES)}
+    torch.cuda.synchronize()
+
+    # N actually produced by the generator
+    with torch.no_grad():
+        from gaussian_transformer_amd.rasterizer import get_backend
+        empty = torch.empty(0, device=dev)
+        N = get_backend().forward(rs, means3D.detach(), shs.detach(), empty, opac.detach(), scales.detach(),
+                                  rots.detach(), empty)[0]
+    K = (D + 1) ** 2
+    HW = W * H
+    ab = algorithmic_bytes(P, N, HW, K, M)
+    kern_stages = [k for k in ab if ab[k] > 0]
+    dominant = max(kern_stages, key=lambda k: stage_ms.get(k, 0.0))
+    dom_ms = stage_ms[dominant]
+    achieved = ab[dominant] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    total_bytes = sum(ab.values())
+    per_stage = {k: {"ms": round(stage_ms.get(k, 0.0), 4), "alg_GB": round(ab[k] / 1e9, 4),
+                     "GBps": round(ab[k] / (stage_ms[k] * 1e-3) / 1e9, 1) if stage_ms.get(k, 0) > 0 else None} for k in ab}
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dominant)
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel_ms": round(dom_ms, 4),
+                "alg_bytes_per_launch": ab[dominant], "stages": per_stage,
+                "whole_path": {"alg_bytes_per_render": total_bytes,
+                               "achieved_GBps": round(total_bytes * value / world / 1e9, 1),
+                               "frac": round(total_bytes * value / world / 1e9 / HBM_PEAK_GBS, 4)},
+                "stage_ms_fwd_total": round(stage_ms.get("fwd.total", 0.0), 4),
+                "stage_ms_bwd_total": round(stage_ms.get("bwd.total", 0.0), 4)}
+
+    # ---- CPU baseline: the float32 CPU restatement (oracle/), all host cores, rank 0, N=1 only ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ref
+        from tests.helpers import oracle_scene
+        r = ref.get("f32")
+        nt = args.cpu_threads or r.max_threads()
+        S = oracle_scene(sc)
+        c0 = time.perf_counter()
+        f = r.forward(S, nthreads=nt)
+        c1 = time.perf_counter()
+        g = r.backward(f, sc.dL_dimage, nthreads=nt)
+        c2 = time.perf_counter()
+        cpu = {"value": round(1.0 / (c2 - c0), 4), "unit": "renders/s", "cores": nt, "kind": "port",
+               "sample": f"1 full forward+backward render of {args.config} (P={P}, {W}x{H}, N={f['num_rendered']}); "
+                         f"forward {c1 - c0:.2f} s, backward {c2 - c1:.2f} s",
+               "fwd_s": round(c1 - c0, 3), "bwd_s": round(c2 - c1, 3)}
+        # same-run parity spot check of the bench inputs against the oracle
+        cpu["rgb_max_abs_diff_vs_gpu"] = float(np.abs(state["color"].detach().cpu().numpy() - f["color"]).max())
+
+    if rank == 0:
+        out = {
+            "metric": "forward+backward renders/sec @1080p, 1M Gaussians; HBM GB/s vs roofline",
+            "value": round(value, 3), "unit": "renders/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.config, "gaussians": P, "width": W, "height": H, "sh_degree": D,
+                       "num_rendered_pairs": int(N), "cameras_per_step": world,
+                       "parallelism": f"dp{world} (one camera per GPU" + (", RCCL all-reduce of gradients)" if world > 1 else ")")},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,90 @@
+"""ctypes binding of libgsr_hip.so (C ABI: include/gsr.h).
+
+This is the Python-side stub a maintainer of the reference would add in place of the pybind11
+module `diff_gaussian_rasterization._C`.  There is NO CPU fallback: if the
+library is missing, cannot be loaded, or a tensor is not on a HIP device, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+GSR_NUM_STAGES = 12
+
+_p = C.c_void_p
+_i32 = C.c_int32
+_f = C.c_float
+_sz = C.c_size_t
+
+SIGNATURES = {
+    "gsr_abi_version": (_i32, []),
+    "gsr_last_error": (C.c_char_p, []),
+    "gsr_workspace_sizes": (_i32, [_i32, _i32, _i32, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
+    "gsr_binning_bytes": (_i32, [C.c_int64, _i32, _i32, C.POINTER(_sz)]),
+    "gsr_forward": (_i32, [_p, _i32, _i32, _i32, _i32, _i32,          # stream P D M W H
+                           _p, _p, _p, _p, _p,                        # bg means3D shs colors opacities
+                           _p, _f, _p, _p,                            # scales mod rotations cov3D
+                           _p, _p, _p, _f, _f,                        # view proj campos tanfovx tanfovy
+                           _i32, _i32, _p, _p,                        # prefiltered debug out_color radii
+                           _p, _sz, ALLOC_FN, _p, _p, _sz,            # geom, bytes, alloc, user, img, bytes
+                           C.POINTER(C.c_int64)]),
+    "gsr_backward": (_i32, [_p, _i32, _i32, _i32, C.c_int64, _i32, _i32,   # stream P D M R W H
+                            _p, _p, _p, _p, _p,                       # bg means3D radii shs colors
+                            _p, _f, _p, _p,                           # scales mod rotations cov3D
+                            _p, _p, _p, _f, _f,                       # view proj campos tanfovx tanfovy
+                            _p, _p, _sz, _p, _sz, _p, _sz, _p, _sz,   # dL_dpix geom binning img bwd (+bytes)
+                            _p, _p, _p, _p, _p, _p, _p, _p,           # 8 gradient outputs
+                            _i32]),
+    "gsr_mark_visible": (_i32, [_p, _i32, _p, _p, _p, _p]),
+    "gsr_debug_read_geom": (_i32, [_p, _i32, _p, _p, _p, _p, _p, _p, _p]),
+    "gsr_debug_read_binning": (_i32, [_p, C.c_int64, _i32, _i32, _p, _p, _p, _p, _p]),
+    "gsr_debug_read_image_state": (_i32, [_p, _i32, _i32, _p, _p, _p]),
+    "gsr_set_profiling": (_i32, [_i32]),
+    "gsr_get_stage_times": (_i32, [C.POINTER(C.c_char_p), C.POINTER(_f)]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class GsrError(RuntimeError):
+    """A native failure of the HIP rasterizer (callers of the reference catch RuntimeError)."""
+
+
+def load() -> C.CDLL:
+    """Loads libgsr_hip.so once.  torch is imported first so that the library binds to the HIP
+    runtime already living in the process (torch ships its own libamdhip64 with the same soname)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        import torch  # noqa: F401  (loads libamdhip64 before ours resolves it)
+        if not os.path.exists(LIB_PATH):
+            raise GsrError(
+                f"HIP extension not built: {LIB_PATH} is missing. Run `python -m gaussian_transformer_amd.build` "
+                "(there is no CPU fallback).")
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise GsrError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)       # AttributeError if the symbol is missing: loud by design
+            fn.restype = res
+            fn.argtypes = args
+        if lib.gsr_abi_version() != 1:
+            raise GsrError(f"libgsr_hip.so ABI version {lib.gsr_abi_version()} != 1")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().gsr_last_error()
+        raise GsrError(f"{what} failed (code {rc}): {msg.decode(errors='replace') if msg else ''}")

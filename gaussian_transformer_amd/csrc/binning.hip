@@ -1,0 +1,115 @@
+// binning.hip -- scan of tiles-touched, (tile, depth) key emission (S7), global radix sort,
+// per-tile range detection (S8).  All HBM-streaming stages.
+//
+// Key emission is work-balanced: a wave owns 64 consecutive Gaussians and its lanes walk the
+// wave's flattened output range (one output pair per lane per step, found by a 6-step search
+// over the wave's 64 scan values with ds_bpermute), so a splat covering a thousand tiles costs
+// the same per pair as one covering four, and every store is a contiguous 64-lane row.
+#include <cstring>  // ROCm 7.2 rocprim/texture_cache_iterator.hpp uses memset without including it
+#include <rocprim/rocprim.hpp>
+
+#include "gsr_device.h"
+#include "gsr_internal.h"
+
+namespace gsr {
+
+hipError_t scan_temp_bytes(int P, size_t *bytes) {
+    size_t tb = 0;
+    hipError_t e = rocprim::inclusive_scan(nullptr, tb, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                           (size_t)(P > 0 ? P : 1), rocprim::plus<uint32_t>(), (hipStream_t)0, false);
+    *bytes = tb;
+    return e;
+}
+
+hipError_t launch_scan(const GeomView &g, int P, hipStream_t s) {
+    size_t tb = g.scan_temp_bytes;
+    return rocprim::inclusive_scan(g.scan_temp, tb, (const uint32_t *)g.tiles, g.offsets, (size_t)P,
+                                   rocprim::plus<uint32_t>(), s, false);
+}
+
+hipError_t sort_temp_bytes(int64_t N, int bits, size_t *bytes) {
+    size_t tb = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tb, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                             (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                             (size_t)(N > 0 ? N : 1), 0u, (unsigned)bits, (hipStream_t)0, false);
+    *bytes = tb;
+    return e;
+}
+
+hipError_t launch_sort(const BinningView &b, int64_t N, int bits, hipStream_t s) {
+    size_t tb = b.sort_temp_bytes;
+    return rocprim::radix_sort_pairs(b.sort_temp, tb, (const uint64_t *)b.keys_unsorted, b.keys_sorted,
+                                     (const uint32_t *)b.point_list_unsorted, b.point_list, (size_t)N, 0u,
+                                     (unsigned)bits, s, false);
+}
+
+__global__ __launch_bounds__(256) void emit_keys_kernel(int P, int gridx, const uint32_t *__restrict__ tiles,
+                                                        const uint32_t *__restrict__ offsets,
+                                                        const uint2 *__restrict__ rect, const float *__restrict__ depth,
+                                                        uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const int lane = threadIdx.x & 63;
+    const int g0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (g0 >= P) return;                                  // wave-uniform
+    const int g = g0 + lane;
+    const int gc = g < P ? g : P - 1;
+    const uint32_t wave_start = g0 > 0 ? offsets[g0 - 1] : 0u;
+    const uint32_t incl = offsets[gc] - wave_start;       // lanes past P repeat the last value
+    const uint32_t cnt = g < P ? tiles[gc] : 0u;
+    const uint32_t excl = incl - cnt;
+    const uint2 rc = rect[gc];
+    const uint32_t dbits = __float_as_uint(depth[gc]);
+    const uint32_t total = __shfl(incl, 63);
+    // wave-uniform trip count: every lane stays active for the cross-lane reads
+    for (uint32_t base = 0; base < total; base += 64) {
+        const uint32_t j = base + lane;
+        int lo = 0;                                       // number of lanes whose incl <= j
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+            const uint32_t v = __shfl(incl, (lo + step - 1) & 63);
+            if (v <= j) lo += step;
+        }
+        const int src = lo & 63;                          // lo == 64 only for j >= total (not stored)
+        const uint32_t e = __shfl(excl, src);
+        const uint32_t rx = __shfl(rc.x, src), ry = __shfl(rc.y, src);
+        const uint32_t db = __shfl(dbits, src);
+        if (j < total) {
+            const uint32_t x0 = rx & 0xffffu, w = (rx >> 16) - x0, y0 = ry & 0xffffu;
+            const uint32_t k = j - e;
+            const uint32_t ty = k / w, tx = k - ty * w;
+            const uint32_t tile = (y0 + ty) * (uint32_t)gridx + (x0 + tx);
+            const size_t o = (size_t)wave_start + j;
+            keys[o] = ((uint64_t)tile << 32) | db;
+            vals[o] = (uint32_t)(g0 + src);
+        }
+    }
+}
+
+hipError_t launch_emit_keys(const GeomView &g, const BinningView &b, int P, int gridx, hipStream_t s) {
+    if (P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(emit_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, gridx, g.tiles, g.offsets, g.rect,
+                       g.depth, b.keys_unsorted, b.point_list_unsorted);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t N, const uint64_t *__restrict__ keys,
+                                                          uint2 *__restrict__ ranges) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const uint32_t t = (uint32_t)(keys[j] >> 32);
+    if (j == 0) {
+        ranges[t].x = 0u;
+    } else {
+        const uint32_t tp = (uint32_t)(keys[j - 1] >> 32);
+        if (tp != t) { ranges[tp].y = (uint32_t)j; ranges[t].x = (uint32_t)j; }
+    }
+    if (j == N - 1) ranges[t].y = (uint32_t)N;
+}
+
+hipError_t launch_ranges(const BinningView &b, const ImageView &im, int64_t N, int T, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)T, s);
+    if (e != hipSuccess || N <= 0) return e;
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, b.keys_sorted, im.ranges);
+    return hipGetLastError();
+}
+
+}  // namespace gsr

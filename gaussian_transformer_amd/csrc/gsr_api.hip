@@ -1,0 +1,364 @@
+// gsr_api.hip -- the C ABI of libgsr_hip.so (include/gsr.h): argument validation, workspace
+// carving, stage sequencing on the caller's stream, error reporting.  Host code only.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/gsr.h"
+#include "gsr_internal.h"
+
+namespace gsr {
+
+static thread_local char g_err[512] = "";
+static thread_local int g_profiling = 0;
+static thread_local float g_stage_ms[GSR_NUM_STAGES] = {0};
+static const char *const k_stage_names[GSR_NUM_STAGES] = {
+    "fwd.preprocess", "fwd.scan", "fwd.readback_N", "fwd.emit_keys", "fwd.sort", "fwd.ranges", "fwd.composite",
+    "bwd.zero_acc", "bwd.composite", "bwd.pergauss", "fwd.total", "bwd.total"};
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr, what)                                                                              \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess) return fail(GSR_ERR_HIP, "%s: %s (%d)", what, hipGetErrorString(_e), (int)_e); \
+    } while (0)
+
+GeomView carve_geom(void *base, int P, size_t scan_tb) {
+    GeomView g;
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += align_up(bytes); return r; };
+    g.rec = (float *)take(n * GSR_REC_FLOATS * sizeof(float));
+    g.depth = (float *)take(n * sizeof(float));
+    g.rect = (uint2 *)take(n * sizeof(uint2));
+    g.tiles = (uint32_t *)take(n * sizeof(uint32_t));
+    g.offsets = (uint32_t *)take(n * sizeof(uint32_t));
+    g.clamped = (uint8_t *)take(n);
+    g.scan_temp = take(scan_tb);
+    g.scan_temp_bytes = scan_tb;
+    g.total_bytes = off;
+    return g;
+}
+
+ImageView carve_image(void *base, int W, int H) {
+    ImageView v;
+    const size_t T = (size_t)((W + GSR_TILE_HOST - 1) / GSR_TILE_HOST) * ((H + GSR_TILE_HOST - 1) / GSR_TILE_HOST);
+    const size_t HW = (size_t)W * H;
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += align_up(bytes); return r; };
+    v.ranges = (uint2 *)take((T > 0 ? T : 1) * sizeof(uint2));
+    v.final_T = (float *)take((HW > 0 ? HW : 1) * sizeof(float));
+    v.n_contrib = (uint32_t *)take((HW > 0 ? HW : 1) * sizeof(uint32_t));
+    v.total_bytes = off;
+    return v;
+}
+
+BinningView carve_binning(void *base, int64_t N, size_t sort_tb) {
+    BinningView b;
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += align_up(bytes); return r; };
+    b.point_list = (uint32_t *)take(n * sizeof(uint32_t));
+    b.keys_sorted = (uint64_t *)take(n * sizeof(uint64_t));
+    b.keys_unsorted = (uint64_t *)take(n * sizeof(uint64_t));
+    b.point_list_unsorted = (uint32_t *)take(n * sizeof(uint32_t));
+    b.sort_temp = take(sort_tb);
+    b.sort_temp_bytes = sort_tb;
+    b.total_bytes = off;
+    return b;
+}
+
+static inline int grid_dim(int px) { return (px + GSR_TILE_HOST - 1) / GSR_TILE_HOST; }
+static inline int key_bits(int W, int H) { return 32 + ceil_log2_u32((uint32_t)(grid_dim(W) * grid_dim(H))); }
+
+struct StageTimer {   // hipEvent pairs on the caller's stream; active only under gsr_set_profiling(1)
+    hipStream_t s;
+    bool on;
+    hipEvent_t ev[GSR_NUM_STAGES + 1];
+    int idx[GSR_NUM_STAGES + 1];
+    int n = 0;
+    StageTimer(hipStream_t s_, bool on_) : s(s_), on(on_) {}
+    void mark(int stage_about_to_start) {
+        if (!on || n > GSR_NUM_STAGES) return;
+        if (hipEventCreate(&ev[n]) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(ev[n], s);
+        idx[n] = stage_about_to_start;
+        n++;
+    }
+    void finish(int total_slot) {   // call after a final mark(-1)
+        if (!on || n < 2) return;
+        (void)hipEventSynchronize(ev[n - 1]);
+        for (int i = 0; i + 1 < n; i++) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            if (idx[i] >= 0) g_stage_ms[idx[i]] = ms;
+        }
+        float tot = 0.f;
+        (void)hipEventElapsedTime(&tot, ev[0], ev[n - 1]);
+        g_stage_ms[total_slot] = tot;
+        for (int i = 0; i < n; i++) (void)hipEventDestroy(ev[i]);
+        n = 0;
+    }
+};
+
+}  // namespace gsr
+
+using namespace gsr;
+
+extern "C" {
+
+int32_t gsr_abi_version(void) { return GSR_ABI_VERSION; }
+const char *gsr_last_error(void) { return g_err; }
+
+int32_t gsr_set_profiling(int32_t enable) { g_profiling = enable ? 1 : 0; return GSR_OK; }
+int32_t gsr_get_stage_times(const char **names, float *ms) {
+    for (int i = 0; i < GSR_NUM_STAGES; i++) {
+        if (names) names[i] = k_stage_names[i];
+        if (ms) ms[i] = g_stage_ms[i];
+    }
+    return GSR_OK;
+}
+
+int32_t gsr_workspace_sizes(int32_t P, int32_t W, int32_t H, size_t *geom_bytes, size_t *img_bytes, size_t *bwd_bytes) {
+    if (P < 0 || W <= 0 || H <= 0) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_workspace_sizes: P=%d W=%d H=%d", P, W, H);
+    if (W > 65535 * GSR_TILE_HOST || H > 65535 * GSR_TILE_HOST) return fail(GSR_ERR_INVALID_ARGUMENT, "image too large");
+    size_t stb = 0;
+    HIP_TRY(scan_temp_bytes(P, &stb), "scan temp query");
+    if (geom_bytes) *geom_bytes = carve_geom(nullptr, P, stb).total_bytes;
+    if (img_bytes) *img_bytes = carve_image(nullptr, W, H).total_bytes;
+    if (bwd_bytes) *bwd_bytes = align_up((size_t)(P > 0 ? P : 1) * GSR_ACC_FLOATS * sizeof(float));
+    return GSR_OK;
+}
+
+int32_t gsr_binning_bytes(int64_t N, int32_t W, int32_t H, size_t *bytes) {
+    if (N < 0 || W <= 0 || H <= 0 || !bytes) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_binning_bytes: bad argument");
+    size_t stb = 0;
+    HIP_TRY(sort_temp_bytes(N, key_bits(W, H), &stb), "sort temp query");
+    *bytes = carve_binning(nullptr, N, stb).total_bytes;
+    return GSR_OK;
+}
+
+int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float *bg,
+                    const float *means3D, const float *shs, const float *colors_precomp, const float *opacities,
+                    const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                    const float *viewmatrix, const float *projmatrix, const float *campos, float tanfovx,
+                    float tanfovy, int32_t prefiltered, int32_t debug, float *out_color, int32_t *radii, void *geom_ws,
+                    size_t geom_bytes, gsr_alloc_fn binning_alloc, void *binning_user, void *img_ws, size_t img_bytes,
+                    int64_t *num_rendered) {
+    (void)prefiltered;   // culled Gaussians are always skipped, as with prefiltered=False (the only value the reference passes)
+    hipStream_t s = (hipStream_t)stream;
+    if (num_rendered) *num_rendered = 0;
+    if (P < 0 || W <= 0 || H <= 0 || !out_color || !bg || !viewmatrix || !projmatrix)
+        return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward: bad sizes or missing bg/matrices/out_color");
+    if (W > 65535 * GSR_TILE_HOST || H > 65535 * GSR_TILE_HOST) return fail(GSR_ERR_INVALID_ARGUMENT, "image too large");
+    const size_t HW = (size_t)W * H;
+    if (P == 0) {   // upstream returns a zero image, not the background, when there is nothing to draw
+        HIP_TRY(hipMemsetAsync(out_color, 0, 3 * HW * sizeof(float), s), "memset out_color");
+        return GSR_OK;
+    }
+    if (!means3D || !opacities || !radii || !geom_ws || !img_ws || !binning_alloc)
+        return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward: missing means3D/opacities/radii/workspaces/allocator");
+    if ((shs != nullptr) == (colors_precomp != nullptr))
+        return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward: exactly one of shs / colors_precomp must be given");
+    if (((scales != nullptr) && (rotations != nullptr)) == (cov3D_precomp != nullptr) || ((scales != nullptr) != (rotations != nullptr)))
+        return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward: exactly one of (scales, rotations) / cov3D_precomp must be given");
+    if (shs) {
+        if (D < 0 || D > 3) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward: SH degree %d not in 0..3", D);
+        if (M < (D + 1) * (D + 1)) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward: M=%d < (D+1)^2=%d", M, (D + 1) * (D + 1));
+        if (!campos) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward: campos required with shs");
+    }
+    size_t stb = 0;
+    HIP_TRY(scan_temp_bytes(P, &stb), "scan temp query");
+    GeomView g = carve_geom(geom_ws, P, stb);
+    ImageView im = carve_image(img_ws, W, H);
+    if (geom_bytes < g.total_bytes) return fail(GSR_ERR_WORKSPACE, "geom workspace %zu < %zu", geom_bytes, g.total_bytes);
+    if (img_bytes < im.total_bytes) return fail(GSR_ERR_WORKSPACE, "image workspace %zu < %zu", img_bytes, im.total_bytes);
+    const int gridx = grid_dim(W), gridy = grid_dim(H), T = gridx * gridy;
+
+    StageTimer tm(s, g_profiling != 0);
+    tm.mark(0);
+    PreprocessArgs pa;
+    pa.P = P; pa.D = D; pa.M = M; pa.W = W; pa.H = H; pa.gridx = gridx; pa.gridy = gridy;
+    pa.means3D = means3D; pa.shs = shs; pa.colors_precomp = colors_precomp; pa.opacities = opacities;
+    pa.scales = scales; pa.rotations = rotations; pa.cov3D_precomp = cov3D_precomp;
+    pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.campos = campos;
+    pa.scale_modifier = scale_modifier; pa.tanfovx = tanfovx; pa.tanfovy = tanfovy; pa.radii = radii; pa.g = g;
+    HIP_TRY(launch_preprocess_fwd(pa, s), "preprocess launch");
+    if (debug) HIP_TRY(hipStreamSynchronize(s), "preprocess");
+    tm.mark(1);
+    HIP_TRY(launch_scan(g, P, s), "scan");
+    if (debug) HIP_TRY(hipStreamSynchronize(s), "scan");
+    tm.mark(2);
+    uint32_t n32 = 0;
+    HIP_TRY(hipMemcpyAsync(&n32, g.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read N");
+    HIP_TRY(hipStreamSynchronize(s), "read N sync");
+    const int64_t N = (int64_t)n32;
+    if (num_rendered) *num_rendered = N;
+
+    size_t sort_tb = 0;
+    const int bits = key_bits(W, H);
+    HIP_TRY(sort_temp_bytes(N, bits, &sort_tb), "sort temp query");
+    BinningView b = carve_binning(nullptr, N, sort_tb);
+    void *bin_ptr = binning_alloc(binning_user, b.total_bytes);
+    if (!bin_ptr) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL for %zu bytes (N=%lld)", b.total_bytes, (long long)N);
+    b = carve_binning(bin_ptr, N, sort_tb);
+    tm.mark(3);
+    if (N > 0) {
+        HIP_TRY(launch_emit_keys(g, b, P, gridx, s), "emit keys launch");
+        if (debug) HIP_TRY(hipStreamSynchronize(s), "emit keys");
+        tm.mark(4);
+        HIP_TRY(launch_sort(b, N, bits, s), "radix sort");
+        if (debug) HIP_TRY(hipStreamSynchronize(s), "radix sort");
+    }
+    tm.mark(5);
+    HIP_TRY(launch_ranges(b, im, N, T, s), "tile ranges");
+    if (debug) HIP_TRY(hipStreamSynchronize(s), "tile ranges");
+    tm.mark(6);
+    CompositeArgs ca;
+    ca.W = W; ca.H = H; ca.gridx = gridx; ca.gridy = gridy; ca.ranges = im.ranges; ca.point_list = b.point_list;
+    ca.rec = g.rec; ca.bg = bg; ca.final_T = im.final_T; ca.n_contrib = im.n_contrib; ca.out_color = out_color;
+    HIP_TRY(launch_composite_fwd(ca, s), "composite launch");
+    if (debug) HIP_TRY(hipStreamSynchronize(s), "composite");
+    tm.mark(-1);
+    tm.finish(10);
+    return GSR_OK;
+}
+
+int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64_t R, int32_t W, int32_t H,
+                     const float *bg, const float *means3D, const int32_t *radii, const float *shs,
+                     const float *colors_precomp, const float *scales, float scale_modifier, const float *rotations,
+                     const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
+                     float tanfovx, float tanfovy, const float *dL_dpix, const void *geom_ws, size_t geom_bytes,
+                     const void *binning_ws, size_t binning_bytes, const void *img_ws, size_t img_bytes, void *bwd_ws,
+                     size_t bwd_bytes, float *dL_dmeans2D, float *dL_dopacity, float *dL_dcolors, float *dL_dmeans3D,
+                     float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drots, int32_t debug) {
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || W <= 0 || H <= 0 || R < 0) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: bad sizes");
+    if (P == 0) return GSR_OK;
+    if (!bg || !means3D || !radii || !viewmatrix || !projmatrix || !dL_dpix || !geom_ws || !img_ws || !bwd_ws ||
+        !dL_dmeans2D || !dL_dopacity || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D)
+        return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: missing input, workspace or gradient buffer");
+    if ((shs != nullptr) == (colors_precomp != nullptr))
+        return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: exactly one of shs / colors_precomp must be given");
+    if (((scales != nullptr) && (rotations != nullptr)) == (cov3D_precomp != nullptr) || ((scales != nullptr) != (rotations != nullptr)))
+        return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: exactly one of (scales, rotations) / cov3D_precomp must be given");
+    if (shs && (!dL_dsh || !campos || D < 0 || D > 3 || M < (D + 1) * (D + 1)))
+        return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: SH inputs inconsistent");
+    if (scales && (!dL_dscales || !dL_drots)) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: dL_dscales/dL_drots required");
+    if (R > 0 && !binning_ws) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: binning workspace missing");
+    size_t stb = 0;
+    HIP_TRY(scan_temp_bytes(P, &stb), "scan temp query");
+    GeomView g = carve_geom(const_cast<void *>(geom_ws), P, stb);
+    ImageView im = carve_image(const_cast<void *>(img_ws), W, H);
+    if (geom_bytes < g.total_bytes) return fail(GSR_ERR_WORKSPACE, "geom workspace %zu < %zu", geom_bytes, g.total_bytes);
+    if (img_bytes < im.total_bytes) return fail(GSR_ERR_WORKSPACE, "image workspace %zu < %zu", img_bytes, im.total_bytes);
+    BinningView b = carve_binning(const_cast<void *>(binning_ws), R, 0);
+    if (R > 0 && binning_bytes < align_up((size_t)R * sizeof(uint32_t)))
+        return fail(GSR_ERR_WORKSPACE, "binning workspace too small for R=%lld", (long long)R);
+    const size_t acc_bytes = (size_t)P * GSR_ACC_FLOATS * sizeof(float);
+    if (bwd_bytes < acc_bytes) return fail(GSR_ERR_WORKSPACE, "backward workspace %zu < %zu", bwd_bytes, acc_bytes);
+    const int gridx = grid_dim(W), gridy = grid_dim(H);
+
+    StageTimer tm(s, g_profiling != 0);
+    tm.mark(7);
+    HIP_TRY(hipMemsetAsync(bwd_ws, 0, acc_bytes, s), "zero accumulators");
+    tm.mark(8);
+    if (R > 0) {
+        CompositeBwdArgs ca;
+        ca.W = W; ca.H = H; ca.gridx = gridx; ca.gridy = gridy; ca.ranges = im.ranges; ca.point_list = b.point_list;
+        ca.rec = g.rec; ca.bg = bg; ca.final_T = im.final_T; ca.n_contrib = im.n_contrib; ca.dL_dpix = dL_dpix;
+        ca.acc = (float *)bwd_ws;
+        HIP_TRY(launch_composite_bwd(ca, s), "composite backward launch");
+        if (debug) HIP_TRY(hipStreamSynchronize(s), "composite backward");
+    }
+    tm.mark(9);
+    PergaussBwdArgs pa;
+    pa.P = P; pa.D = D; pa.M = M; pa.W = W; pa.H = H; pa.means3D = means3D; pa.shs = shs; pa.colors_precomp = colors_precomp;
+    pa.scales = scales; pa.rotations = rotations; pa.cov3D_precomp = cov3D_precomp; pa.viewmatrix = viewmatrix;
+    pa.projmatrix = projmatrix; pa.campos = campos; pa.scale_modifier = scale_modifier; pa.tanfovx = tanfovx;
+    pa.tanfovy = tanfovy; pa.radii = radii; pa.clamped = g.clamped; pa.acc = (const float *)bwd_ws;
+    pa.dL_dmeans2D = dL_dmeans2D; pa.dL_dopacity = dL_dopacity; pa.dL_dcolors = dL_dcolors; pa.dL_dmeans3D = dL_dmeans3D;
+    pa.dL_dcov3D = dL_dcov3D; pa.dL_dsh = dL_dsh; pa.dL_dscales = dL_dscales; pa.dL_drots = dL_drots;
+    HIP_TRY(launch_pergauss_bwd(pa, s), "per-Gaussian backward launch");
+    if (debug) HIP_TRY(hipStreamSynchronize(s), "per-Gaussian backward");
+    tm.mark(-1);
+    tm.finish(11);
+    return GSR_OK;
+}
+
+int32_t gsr_mark_visible(gsr_stream_t stream, int32_t P, const float *means3D, const float *viewmatrix,
+                         const float *projmatrix, uint8_t *present) {
+    (void)projmatrix;
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_mark_visible: bad argument");
+    HIP_TRY(launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream), "mark_visible launch");
+    return GSR_OK;
+}
+
+int32_t gsr_debug_read_geom(gsr_stream_t stream, int32_t P, const void *geom_ws, float *depth, float *xy,
+                            float *conic_opacity, float *rgb, uint32_t *tiles_touched, uint8_t *clamped) {
+    hipStream_t s = (hipStream_t)stream;
+    if (P <= 0) return GSR_OK;
+    size_t stb = 0;
+    HIP_TRY(scan_temp_bytes(P, &stb), "scan temp query");
+    GeomView g = carve_geom(const_cast<void *>(geom_ws), P, stb);
+    HIP_TRY(hipStreamSynchronize(s), "sync");
+    float *rec = (float *)malloc((size_t)P * GSR_REC_FLOATS * sizeof(float));
+    uint8_t *cl = (uint8_t *)malloc((size_t)P);
+    if (!rec || !cl) { free(rec); free(cl); return fail(GSR_ERR_ALLOC, "host malloc"); }
+    hipError_t e = hipMemcpy(rec, g.rec, (size_t)P * GSR_REC_FLOATS * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(cl, g.clamped, (size_t)P, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && tiles_touched) e = hipMemcpy(tiles_touched, g.tiles, (size_t)P * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && depth) e = hipMemcpy(depth, g.depth, (size_t)P * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { free(rec); free(cl); return fail(GSR_ERR_HIP, "debug copy: %s", hipGetErrorString(e)); }
+    for (int i = 0; i < P; i++) {
+        const float *r = rec + (size_t)i * GSR_REC_FLOATS;
+        if (xy) { xy[2 * i] = r[0]; xy[2 * i + 1] = r[1]; }
+        if (conic_opacity) { conic_opacity[4 * i] = r[2]; conic_opacity[4 * i + 1] = r[3]; conic_opacity[4 * i + 2] = r[4]; conic_opacity[4 * i + 3] = r[5]; }
+        if (rgb) { rgb[3 * i] = r[6]; rgb[3 * i + 1] = r[7]; rgb[3 * i + 2] = r[8]; }
+        if (clamped) { clamped[3 * i] = cl[i] & 1; clamped[3 * i + 1] = (cl[i] >> 1) & 1; clamped[3 * i + 2] = (cl[i] >> 2) & 1; }
+    }
+    free(rec); free(cl);
+    return GSR_OK;
+}
+
+int32_t gsr_debug_read_binning(gsr_stream_t stream, int64_t N, int32_t W, int32_t H, const void *binning_ws,
+                               const void *img_ws, uint64_t *keys_sorted, uint32_t *point_list, uint32_t *ranges) {
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipStreamSynchronize(s), "sync");
+    if (N > 0 && binning_ws) {
+        BinningView b = carve_binning(const_cast<void *>(binning_ws), N, 0);
+        if (keys_sorted) HIP_TRY(hipMemcpy(keys_sorted, b.keys_sorted, (size_t)N * 8, hipMemcpyDeviceToHost), "copy keys");
+        if (point_list) HIP_TRY(hipMemcpy(point_list, b.point_list, (size_t)N * 4, hipMemcpyDeviceToHost), "copy point list");
+    }
+    if (ranges && img_ws) {
+        ImageView im = carve_image(const_cast<void *>(img_ws), W, H);
+        const size_t T = (size_t)grid_dim(W) * grid_dim(H);
+        HIP_TRY(hipMemcpy(ranges, im.ranges, T * sizeof(uint2), hipMemcpyDeviceToHost), "copy ranges");
+    }
+    return GSR_OK;
+}
+
+int32_t gsr_debug_read_image_state(gsr_stream_t stream, int32_t W, int32_t H, const void *img_ws, float *final_T,
+                                   uint32_t *n_contrib) {
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipStreamSynchronize(s), "sync");
+    ImageView im = carve_image(const_cast<void *>(img_ws), W, H);
+    const size_t HW = (size_t)W * H;
+    if (final_T) HIP_TRY(hipMemcpy(final_T, im.final_T, HW * 4, hipMemcpyDeviceToHost), "copy final_T");
+    if (n_contrib) HIP_TRY(hipMemcpy(n_contrib, im.n_contrib, HW * 4, hipMemcpyDeviceToHost), "copy n_contrib");
+    return GSR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,221 @@
+// gsr_device.h -- per-Gaussian math shared by the forward and backward HIP kernels (gfx950).
+//
+// Stages S1-S6 / S11-S13 of SURVEY.md 8a.  The operation order matches oracle/gsr_ref.c and
+// these translation units are compiled with -ffp-contract=off, so that the discrete outputs of
+// the per-Gaussian stage (radius, tile rectangle, depth key) are bit-identical to the float32
+// CPU restatement: sqrt and division are IEEE-correct under hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GSR_TILE 16
+#define GSR_NEAR_Z 0.2f
+#define GSR_W_EPS 0.0000001f
+#define GSR_FOV_CLAMP 1.3f
+#define GSR_DILATION 0.3f
+#define GSR_LAMBDA_FLOOR 0.1f
+#define GSR_SIGMA_EXTENT 3.0f
+#define GSR_ALPHA_MAX 0.99f
+#define GSR_ALPHA_MIN (1.0f / 255.0f)
+#define GSR_T_MIN 0.0001f
+#define GSR_DENOM_EPS 0.0000001f
+
+// SH basis constants (utils/sh_utils.py:26-43 of the reference)
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+#define SH_C2_0 1.0925484305920792f
+#define SH_C2_1 -1.0925484305920792f
+#define SH_C2_2 0.31539156525252005f
+#define SH_C2_3 -1.0925484305920792f
+#define SH_C2_4 0.5462742152960396f
+#define SH_C3_0 -0.5900435899266435f
+#define SH_C3_1 2.890611442640554f
+#define SH_C3_2 -0.4570457994644658f
+#define SH_C3_3 0.3731763325901154f
+#define SH_C3_4 -0.4570457994644658f
+#define SH_C3_5 1.445305721320277f
+#define SH_C3_6 -0.5900435899266435f
+
+namespace gsr {
+
+// x' = m[0]x + m[4]y + m[8]z + m[12]  (scene/cameras.py:54-57 memory layout)
+__device__ __forceinline__ void xform4x3(const float *__restrict__ m, const float p[3], float o[3]) {
+    o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+}
+__device__ __forceinline__ void xform4x4(const float *__restrict__ m, const float p[3], float o[4]) {
+    xform4x3(m, p, o);
+    o[3] = m[3] * p[0] + m[7] * p[1] + m[11] * p[2] + m[15];
+}
+
+// rotation of an (r,x,y,z) quaternion used as-is (utils/general_utils.py:85-98)
+__device__ __forceinline__ void quat_to_rot(const float q[4], float Rm[3][3]) {
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    Rm[0][0] = 1.f - 2.f * (y * y + z * z);
+    Rm[0][1] = 2.f * (x * y - r * z);
+    Rm[0][2] = 2.f * (x * z + r * y);
+    Rm[1][0] = 2.f * (x * y + r * z);
+    Rm[1][1] = 1.f - 2.f * (x * x + z * z);
+    Rm[1][2] = 2.f * (y * z - r * x);
+    Rm[2][0] = 2.f * (x * z - r * y);
+    Rm[2][1] = 2.f * (y * z + r * x);
+    Rm[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+// S2: Sigma = (R S)(R S)^T packed xx,xy,xz,yy,yz,zz
+__device__ __forceinline__ void cov3d_from_scale_rot(const float s[3], float mod, const float q[4], float c6[6]) {
+    float Rm[3][3], Mm[3][3];
+    quat_to_rot(q, Rm);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Mm[i][j] = Rm[i][j] * (mod * s[j]);
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = i; j < 3; j++) c6[k++] = Mm[i][0] * Mm[j][0] + Mm[i][1] * Mm[j][1] + Mm[i][2] * Mm[j][2];
+}
+
+struct Ewa {
+    float t[3];
+    bool clampx, clampy;
+    float T[2][3];
+    float a, b, c;
+    float fx, fy;
+    float Wm[3][3];
+    float TS[2][3];
+};
+
+// S3: EWA projection of the 3D covariance
+__device__ __forceinline__ void ewa_project(const float pview[3], const float c6[6], const float *__restrict__ V,
+                                            float tanfovx, float tanfovy, int W, int H, Ewa &e) {
+    const float fx = (float)W / (2.f * tanfovx), fy = (float)H / (2.f * tanfovy);
+    const float limx = GSR_FOV_CLAMP * tanfovx, limy = GSR_FOV_CLAMP * tanfovy;
+    const float tz = pview[2];
+    const float txtz = pview[0] / tz, tytz = pview[1] / tz;
+    e.clampx = (txtz < -limx) || (txtz > limx);
+    e.clampy = (tytz < -limy) || (tytz > limy);
+    const float cx = txtz < -limx ? -limx : (txtz > limx ? limx : txtz);
+    const float cy = tytz < -limy ? -limy : (tytz > limy ? limy : tytz);
+    const float tx = cx * tz, ty = cy * tz;
+    e.t[0] = tx; e.t[1] = ty; e.t[2] = tz;
+    e.fx = fx; e.fy = fy;
+    const float J00 = fx / tz, J02 = -(fx * tx) / (tz * tz);
+    const float J11 = fy / tz, J12 = -(fy * ty) / (tz * tz);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) e.Wm[r][c] = V[c * 4 + r];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        e.T[0][k] = J00 * e.Wm[0][k] + J02 * e.Wm[2][k];
+        e.T[1][k] = J11 * e.Wm[1][k] + J12 * e.Wm[2][k];
+    }
+    const float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) e.TS[i][k] = e.T[i][0] * S[0][k] + e.T[i][1] * S[1][k] + e.T[i][2] * S[2][k];
+    e.a = e.TS[0][0] * e.T[0][0] + e.TS[0][1] * e.T[0][1] + e.TS[0][2] * e.T[0][2] + GSR_DILATION;
+    e.b = e.TS[0][0] * e.T[1][0] + e.TS[0][1] * e.T[1][1] + e.TS[0][2] * e.T[1][2];
+    e.c = e.TS[1][0] * e.T[1][0] + e.TS[1][1] * e.T[1][1] + e.TS[1][2] * e.T[1][2] + GSR_DILATION;
+}
+
+// SH basis b[0..(D+1)^2) at unit direction d (sign pattern of utils/sh_utils.py:74-100)
+template <int D>
+__device__ __forceinline__ void sh_basis(const float d[3], float b[16]) {
+    const float x = d[0], y = d[1], z = d[2];
+    b[0] = SH_C0;
+    if (D > 0) {
+        b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x;
+        if (D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b[4] = SH_C2_0 * xy; b[5] = SH_C2_1 * yz; b[6] = SH_C2_2 * (2.f * zz - xx - yy);
+            b[7] = SH_C2_3 * xz; b[8] = SH_C2_4 * (xx - yy);
+            if (D > 2) {
+                b[9] = SH_C3_0 * y * (3.f * xx - yy);
+                b[10] = SH_C3_1 * xy * z;
+                b[11] = SH_C3_2 * y * (4.f * zz - xx - yy);
+                b[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                b[13] = SH_C3_4 * x * (4.f * zz - xx - yy);
+                b[14] = SH_C3_5 * z * (xx - yy);
+                b[15] = SH_C3_6 * x * (xx - 3.f * yy);
+            }
+        }
+    }
+}
+
+// d(basis_k)/d(x,y,z), x,y,z independent; entries not listed are zero
+template <int D>
+__device__ __forceinline__ void sh_basis_grad(const float d[3], float g[16][3]) {
+    const float x = d[0], y = d[1], z = d[2];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { g[k][0] = 0.f; g[k][1] = 0.f; g[k][2] = 0.f; }
+    if (D > 0) {
+        g[1][1] = -SH_C1; g[2][2] = SH_C1; g[3][0] = -SH_C1;
+        if (D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z;
+            g[4][0] = SH_C2_0 * y; g[4][1] = SH_C2_0 * x;
+            g[5][1] = SH_C2_1 * z; g[5][2] = SH_C2_1 * y;
+            g[6][0] = SH_C2_2 * -2.f * x; g[6][1] = SH_C2_2 * -2.f * y; g[6][2] = SH_C2_2 * 4.f * z;
+            g[7][0] = SH_C2_3 * z; g[7][2] = SH_C2_3 * x;
+            g[8][0] = SH_C2_4 * 2.f * x; g[8][1] = SH_C2_4 * -2.f * y;
+            if (D > 2) {
+                g[9][0] = SH_C3_0 * 6.f * x * y; g[9][1] = SH_C3_0 * (3.f * xx - 3.f * yy);
+                g[10][0] = SH_C3_1 * y * z; g[10][1] = SH_C3_1 * x * z; g[10][2] = SH_C3_1 * x * y;
+                g[11][0] = SH_C3_2 * -2.f * x * y; g[11][1] = SH_C3_2 * (4.f * zz - xx - 3.f * yy);
+                g[11][2] = SH_C3_2 * 8.f * y * z;
+                g[12][0] = SH_C3_3 * -6.f * x * z; g[12][1] = SH_C3_3 * -6.f * y * z;
+                g[12][2] = SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy);
+                g[13][0] = SH_C3_4 * (4.f * zz - 3.f * xx - yy); g[13][1] = SH_C3_4 * -2.f * x * y;
+                g[13][2] = SH_C3_4 * 8.f * x * z;
+                g[14][0] = SH_C3_5 * 2.f * x * z; g[14][1] = SH_C3_5 * -2.f * y * z; g[14][2] = SH_C3_5 * (xx - yy);
+                g[15][0] = SH_C3_6 * (3.f * xx - 3.f * yy); g[15][1] = SH_C3_6 * -6.f * x * y;
+            }
+        }
+    }
+}
+
+// clamp(int(v), 0, hi) with C truncation; NaN and negatives -> 0
+__device__ __forceinline__ int clampi_from_float(float v, int hi) {
+    if (!(v > 0.f)) return 0;
+    if (v >= (float)hi) return hi;
+    return (int)v;
+}
+
+// S5 tile rectangle
+__device__ __forceinline__ void tile_rect(float px, float py, int radius, int gridx, int gridy, int &x0, int &y0,
+                                          int &x1, int &y1) {
+    const float r = (float)radius;
+    x0 = clampi_from_float((px - r) / (float)GSR_TILE, gridx);
+    y0 = clampi_from_float((py - r) / (float)GSR_TILE, gridy);
+    x1 = clampi_from_float((px + r + (float)(GSR_TILE - 1)) / (float)GSR_TILE, gridx);
+    y1 = clampi_from_float((py + r + (float)(GSR_TILE - 1)) / (float)GSR_TILE, gridy);
+}
+
+// Load the first 3*K floats of one Gaussian's SH row [M,3] into c[].  16-byte vector loads when
+// the row stride keeps every row 16-byte aligned (M = 4, 8, 12, 16 ...), scalar loads otherwise.
+template <int K>
+__device__ __forceinline__ void load_sh_row(const float *__restrict__ shs, size_t i, int M, float c[3 * K + 3]) {
+    const float *row = shs + i * (size_t)M * 3;
+    if (((M * 3) & 3) == 0 && ((reinterpret_cast<uintptr_t>(shs) & 15) == 0)) {
+        const float4 *r4 = reinterpret_cast<const float4 *>(row);
+        constexpr int NV = (3 * K + 3) / 4;
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const float4 t = r4[v];
+            c[4 * v] = t.x;
+            if (4 * v + 1 < 3 * K + 3) c[4 * v + 1] = t.y;
+            if (4 * v + 2 < 3 * K + 3) c[4 * v + 2] = t.z;
+            if (4 * v + 3 < 3 * K + 3) c[4 * v + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < 3 * K; v++) c[v] = row[v];
+    }
+}
+
+}  // namespace gsr

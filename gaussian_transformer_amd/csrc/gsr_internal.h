@@ -1,0 +1,112 @@
+// gsr_internal.h -- workspace layouts and kernel launchers shared by the translation units of
+// libgsr_hip.so.  Nothing here is part of the public ABI (include/gsr.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define GSR_TILE_HOST 16   // tile edge in pixels (== GSR_TILE of gsr_device.h)
+
+namespace gsr {
+
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline int ceil_log2_u32(uint32_t x) { int b = 0; while ((1u << b) < x && b < 31) b++; return b; }
+
+// Per-Gaussian record gathered by the compositing kernels: 12 floats = 3 x float4.
+//   [0] px  [1] py  [2] conic.xx  [3] conic.xy | [4] conic.yy [5] opacity [6] r [7] g | [8] b [9] depth [10..11] -
+#define GSR_REC_FLOATS 12
+// Gradient accumulator of the reverse compositing pass: one 64-byte row per Gaussian so that the
+// nine atomics of one (tile, Gaussian) pair fall into a single memory-side atomic request.
+//   [0..2] dL/drgb  [3..4] dL/dmean2D (NDC)  [5..7] dL/dconic (xx, xy-half, yy)  [8] dL/dopacity
+#define GSR_ACC_FLOATS 16
+
+struct GeomView {          // per-Gaussian state, P entries each
+    float *rec;            // [P][12]
+    float *depth;          // [P]
+    uint2 *rect;           // [P] (x0 | x1<<16, y0 | y1<<16)
+    uint32_t *tiles;       // [P] tiles touched
+    uint32_t *offsets;     // [P] inclusive scan of tiles
+    uint8_t *clamped;      // [P] bit ch set iff SH colour channel ch was clamped at 0
+    void *scan_temp;
+    size_t scan_temp_bytes;
+    size_t total_bytes;
+};
+GeomView carve_geom(void *base, int P, size_t scan_temp_bytes);
+
+struct ImageView {
+    uint2 *ranges;         // [T]
+    float *final_T;        // [H*W]
+    uint32_t *n_contrib;   // [H*W]
+    size_t total_bytes;
+};
+ImageView carve_image(void *base, int W, int H);
+
+struct BinningView {
+    uint32_t *point_list;        // [N] sorted Gaussian ids           (read by backward)
+    uint64_t *keys_sorted;       // [N]
+    uint64_t *keys_unsorted;     // [N]
+    uint32_t *point_list_unsorted;  // [N]
+    void *sort_temp;
+    size_t sort_temp_bytes;
+    size_t total_bytes;
+};
+BinningView carve_binning(void *base, int64_t N, size_t sort_temp_bytes);
+
+struct PreprocessArgs {
+    int P, D, M, W, H, gridx, gridy;
+    const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+    const float *viewmatrix, *projmatrix, *campos;
+    float scale_modifier, tanfovx, tanfovy;
+    int *radii;
+    GeomView g;
+};
+hipError_t launch_preprocess_fwd(const PreprocessArgs &a, hipStream_t s);
+
+hipError_t scan_temp_bytes(int P, size_t *bytes);
+hipError_t launch_scan(const GeomView &g, int P, hipStream_t s);
+
+hipError_t sort_temp_bytes(int64_t N, int bits, size_t *bytes);
+hipError_t launch_emit_keys(const GeomView &g, const BinningView &b, int P, int gridx, hipStream_t s);
+hipError_t launch_sort(const BinningView &b, int64_t N, int bits, hipStream_t s);
+hipError_t launch_ranges(const BinningView &b, const ImageView &im, int64_t N, int T, hipStream_t s);
+
+struct CompositeArgs {
+    int W, H, gridx, gridy;
+    const uint2 *ranges;
+    const uint32_t *point_list;
+    const float *rec;
+    const float *bg;
+    float *final_T;
+    uint32_t *n_contrib;
+    float *out_color;
+};
+hipError_t launch_composite_fwd(const CompositeArgs &a, hipStream_t s);
+
+struct CompositeBwdArgs {
+    int W, H, gridx, gridy;
+    const uint2 *ranges;
+    const uint32_t *point_list;
+    const float *rec;
+    const float *bg;
+    const float *final_T;
+    const uint32_t *n_contrib;
+    const float *dL_dpix;
+    float *acc;   // [P][16], zeroed
+};
+hipError_t launch_composite_bwd(const CompositeBwdArgs &a, hipStream_t s);
+
+struct PergaussBwdArgs {
+    int P, D, M, W, H;
+    const float *means3D, *shs, *colors_precomp, *scales, *rotations, *cov3D_precomp;
+    const float *viewmatrix, *projmatrix, *campos;
+    float scale_modifier, tanfovx, tanfovy;
+    const int *radii;
+    const uint8_t *clamped;
+    const float *acc;
+    float *dL_dmeans2D, *dL_dopacity, *dL_dcolors, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drots;
+};
+hipError_t launch_pergauss_bwd(const PergaussBwdArgs &a, hipStream_t s);
+
+hipError_t launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s);
+
+}  // namespace gsr

@@ -1,0 +1,185 @@
+// pergauss_bwd.hip -- per-Gaussian backward chain (S11-S13), one fused kernel, one lane per
+// Gaussian: conic -> 2D covariance -> 3D covariance and mean (through the EWA Jacobian),
+// NDC mean gradient -> mean3D (perspective divide), colour -> SH coefficients and view
+// direction, 3D covariance -> scale and quaternion.  Every output element is written exactly
+// once (zeros for culled Gaussians), so no gradient buffer needs a zero-fill.
+// HBM-streaming: reads 64 (accumulator row) + 44 + 12*K bytes, writes 64 + 12*M bytes per
+// Gaussian.  Compiled with -ffp-contract=off to track oracle/gsr_ref.c.
+#include "gsr_device.h"
+#include "gsr_internal.h"
+
+namespace gsr {
+
+template <int D>
+__global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.P) return;
+    const size_t si = (size_t)i;
+    constexpr int K = (D + 1) * (D + 1);
+    const bool visible = a.radii[si] > 0;
+
+    float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dcol[3] = {0.f, 0.f, 0.f}, dm2[2] = {0.f, 0.f}, dop = 0.f;
+    float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
+
+    if (visible) {
+        const float4 *acc4 = reinterpret_cast<const float4 *>(a.acc) + 4 * si;
+        const float4 A0 = acc4[0], A1 = acc4[1];
+        const float A8 = a.acc[GSR_ACC_FLOATS * si + 8];
+        dcol[0] = A0.x; dcol[1] = A0.y; dcol[2] = A0.z;
+        dm2[0] = A0.w; dm2[1] = A1.x;
+        const float gA = A1.y, gB = A1.z, gC = A1.w;
+        dop = A8;
+
+        const float p[3] = {a.means3D[3 * si], a.means3D[3 * si + 1], a.means3D[3 * si + 2]};
+        float pv[3];
+        xform4x3(a.viewmatrix, p, pv);
+        float c6[6], s[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f};
+        if (a.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * si + k];
+        } else {
+            s[0] = a.scales[3 * si]; s[1] = a.scales[3 * si + 1]; s[2] = a.scales[3 * si + 2];
+            const float4 q4 = reinterpret_cast<const float4 *>(a.rotations)[si];
+            q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+            cov3d_from_scale_rot(s, a.scale_modifier, q, c6);
+        }
+        // ---- S11 ----
+        Ewa e;
+        ewa_project(pv, c6, a.viewmatrix, a.tanfovx, a.tanfovy, a.W, a.H, e);
+        const float ea = e.a, eb = e.b, ec = e.c;
+        const float det = ea * ec - eb * eb;
+        const float d2inv = 1.f / (det * det + GSR_DENOM_EPS);
+        if (d2inv != 0.f) {
+            const float dL_da = d2inv * (-ec * ec * gA + 2.f * eb * ec * gB + (det - ea * ec) * gC);
+            const float dL_dc = d2inv * (-ea * ea * gC + 2.f * ea * eb * gB + (det - ea * ec) * gA);
+            const float dL_db = d2inv * 2.f * (eb * ec * gA - (det + 2.f * eb * eb) * gB + ea * eb * gC);
+            const float(*Tm)[3] = e.T;
+            dcov[0] = Tm[0][0] * Tm[0][0] * dL_da + Tm[0][0] * Tm[1][0] * dL_db + Tm[1][0] * Tm[1][0] * dL_dc;
+            dcov[3] = Tm[0][1] * Tm[0][1] * dL_da + Tm[0][1] * Tm[1][1] * dL_db + Tm[1][1] * Tm[1][1] * dL_dc;
+            dcov[5] = Tm[0][2] * Tm[0][2] * dL_da + Tm[0][2] * Tm[1][2] * dL_db + Tm[1][2] * Tm[1][2] * dL_dc;
+            dcov[1] = 2.f * Tm[0][0] * Tm[0][1] * dL_da + (Tm[0][0] * Tm[1][1] + Tm[0][1] * Tm[1][0]) * dL_db + 2.f * Tm[1][0] * Tm[1][1] * dL_dc;
+            dcov[2] = 2.f * Tm[0][0] * Tm[0][2] * dL_da + (Tm[0][0] * Tm[1][2] + Tm[0][2] * Tm[1][0]) * dL_db + 2.f * Tm[1][0] * Tm[1][2] * dL_dc;
+            dcov[4] = 2.f * Tm[0][2] * Tm[0][1] * dL_da + (Tm[0][1] * Tm[1][2] + Tm[0][2] * Tm[1][1]) * dL_db + 2.f * Tm[1][1] * Tm[1][2] * dL_dc;
+            float dT[2][3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                dT[0][k] = 2.f * dL_da * e.TS[0][k] + dL_db * e.TS[1][k];
+                dT[1][k] = dL_db * e.TS[0][k] + 2.f * dL_dc * e.TS[1][k];
+            }
+            float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                dJ00 += dT[0][k] * e.Wm[0][k]; dJ02 += dT[0][k] * e.Wm[2][k];
+                dJ11 += dT[1][k] * e.Wm[1][k]; dJ12 += dT[1][k] * e.Wm[2][k];
+            }
+            const float tz = 1.f / e.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+            const float dtx = (e.clampx ? 0.f : 1.f) * (-e.fx * tz2 * dJ02);
+            const float dty = (e.clampy ? 0.f : 1.f) * (-e.fy * tz2 * dJ12);
+            const float dtz = -e.fx * tz2 * dJ00 - e.fy * tz2 * dJ11 + 2.f * e.fx * e.t[0] * tz3 * dJ02 + 2.f * e.fy * e.t[1] * tz3 * dJ12;
+#pragma unroll
+            for (int k = 0; k < 3; k++) dmean[k] += e.Wm[0][k] * dtx + e.Wm[1][k] * dty + e.Wm[2][k] * dtz;
+        }
+        // ---- S12a ----
+        {
+            float ph[4];
+            xform4x4(a.projmatrix, p, ph);
+            const float mw = 1.f / (ph[3] + GSR_W_EPS);
+            const float mul1 = ph[0] * mw * mw, mul2 = ph[1] * mw * mw;
+            const float *Pm = a.projmatrix;
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                dmean[k] += (Pm[4 * k] * mw - Pm[4 * k + 3] * mul1) * dm2[0] + (Pm[4 * k + 1] * mw - Pm[4 * k + 3] * mul2) * dm2[1];
+        }
+        // ---- S12b ----
+        if (a.shs) {
+            const float v[3] = {p[0] - a.campos[0], p[1] - a.campos[1], p[2] - a.campos[2]};
+            const float len2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], il = 1.f / sqrtf(len2);
+            const float dir[3] = {v[0] * il, v[1] * il, v[2] * il};
+            float bas[16], bg3[16][3];
+            sh_basis<D>(dir, bas);
+            sh_basis_grad<D>(dir, bg3);
+            float c[3 * K + 3];
+            load_sh_row<K>(a.shs, si, a.M, c);
+            const uint8_t cl = a.clamped[si];
+            float ddir[3] = {0.f, 0.f, 0.f};
+            float *out = a.dL_dsh + si * (size_t)a.M * 3;
+            float gch[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) gch[ch] = ((cl >> ch) & 1) ? 0.f : dcol[ch];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+                for (int k = 0; k < K; k++)
+#pragma unroll
+                    for (int ax = 0; ax < 3; ax++) ddir[ax] += bg3[k][ax] * c[k * 3 + ch] * gch[ch];
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                out[k * 3 + 0] = bas[k] * gch[0]; out[k * 3 + 1] = bas[k] * gch[1]; out[k * 3 + 2] = bas[k] * gch[2];
+            }
+            for (int k = 3 * K; k < 3 * a.M; k++) out[k] = 0.f;
+            const float dot = dir[0] * ddir[0] + dir[1] * ddir[1] + dir[2] * ddir[2];
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) dmean[ax] += (ddir[ax] - dir[ax] * dot) * il;
+        }
+        // ---- S13 ----
+        if (!a.cov3D_precomp) {
+            float Rm[3][3];
+            quat_to_rot(q, Rm);
+            const float sv[3] = {a.scale_modifier * s[0], a.scale_modifier * s[1], a.scale_modifier * s[2]};
+            const float Ds[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                                    {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                                    {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+            float dM[3][3], dR[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    float accv = 0.f;
+#pragma unroll
+                    for (int l = 0; l < 3; l++) accv += Ds[r][l] * Rm[l][j] * sv[j];
+                    dM[r][j] = 2.f * accv;
+                }
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                float accv = 0.f;
+#pragma unroll
+                for (int r = 0; r < 3; r++) { accv += Rm[r][j] * dM[r][j]; dR[r][j] = dM[r][j] * sv[j]; }
+                dscale[j] = a.scale_modifier * accv;
+            }
+            const float r = q[0], x = q[1], y = q[2], z = q[3];
+            drot[0] = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+            drot[1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] - 2.f * x * dR[2][2]);
+            drot[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
+            drot[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+        }
+    } else if (a.shs) {
+        float *out = a.dL_dsh + si * (size_t)a.M * 3;
+        for (int k = 0; k < 3 * a.M; k++) out[k] = 0.f;
+    }
+
+    a.dL_dmeans2D[3 * si] = dm2[0]; a.dL_dmeans2D[3 * si + 1] = dm2[1]; a.dL_dmeans2D[3 * si + 2] = 0.f;
+    a.dL_dopacity[si] = dop;
+    a.dL_dcolors[3 * si] = dcol[0]; a.dL_dcolors[3 * si + 1] = dcol[1]; a.dL_dcolors[3 * si + 2] = dcol[2];
+    a.dL_dmeans3D[3 * si] = dmean[0]; a.dL_dmeans3D[3 * si + 1] = dmean[1]; a.dL_dmeans3D[3 * si + 2] = dmean[2];
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * si + k] = dcov[k];
+    if (a.dL_dscales) {
+        a.dL_dscales[3 * si] = dscale[0]; a.dL_dscales[3 * si + 1] = dscale[1]; a.dL_dscales[3 * si + 2] = dscale[2];
+        reinterpret_cast<float4 *>(a.dL_drots)[si] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+    }
+}
+
+hipError_t launch_pergauss_bwd(const PergaussBwdArgs &a, hipStream_t s) {
+    if (a.P <= 0) return hipSuccess;
+    const dim3 grid((a.P + 255) / 256), block(256);
+    switch (a.shs ? a.D : 0) {
+        case 0: hipLaunchKernelGGL(pergauss_bwd_kernel<0>, grid, block, 0, s, a); break;
+        case 1: hipLaunchKernelGGL(pergauss_bwd_kernel<1>, grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL(pergauss_bwd_kernel<2>, grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL(pergauss_bwd_kernel<3>, grid, block, 0, s, a); break;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace gsr

@@ -1,0 +1,130 @@
+// preprocess.hip -- per-Gaussian forward stage (S1-S6): cull, 3D covariance, EWA projection,
+// conic + radius, pixel centre + tile rectangle, SH colour.  One lane per Gaussian, wave64,
+// 256-thread workgroups.  HBM-streaming: reads 44 + 12*K bytes, writes 48 (record) + 4 (depth)
+// + 8 (rect) + 4 (tiles) + 4 (radii) + 1 (clamp mask) per Gaussian.
+// Compiled with -ffp-contract=off: discrete outputs are bit-identical to oracle/gsr_ref.c.
+#include "gsr_device.h"
+#include "gsr_internal.h"
+
+namespace gsr {
+
+template <int D>
+__global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreprocessArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.P) return;
+    const size_t si = (size_t)i;
+
+    // defaults for a culled Gaussian
+    int radius_out = 0;
+    uint32_t tiles_out = 0;
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+    uint2 rect_out = make_uint2(0u, 0u);
+    uint8_t clamp_out = 0;
+    float depth_out = 0.f;
+
+    const float p[3] = {a.means3D[3 * si], a.means3D[3 * si + 1], a.means3D[3 * si + 2]};
+    float pv[3];
+    xform4x3(a.viewmatrix, p, pv);
+    if (pv[2] > GSR_NEAR_Z) {                                                       // S1
+        float ph[4];
+        xform4x4(a.projmatrix, p, ph);
+        const float pw = 1.f / (ph[3] + GSR_W_EPS);
+        const float ndcx = ph[0] * pw, ndcy = ph[1] * pw;
+        float c6[6];
+        if (a.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * si + k];
+        } else {                                                                    // S2
+            const float s[3] = {a.scales[3 * si], a.scales[3 * si + 1], a.scales[3 * si + 2]};
+            const float4 q4 = reinterpret_cast<const float4 *>(a.rotations)[si];
+            const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+            cov3d_from_scale_rot(s, a.scale_modifier, q, c6);
+        }
+        Ewa e;
+        ewa_project(pv, c6, a.viewmatrix, a.tanfovx, a.tanfovy, a.W, a.H, e);       // S3
+        const float det = e.a * e.c - e.b * e.b;                                    // S4
+        if (det != 0.f) {
+            const float det_inv = 1.f / det;
+            const float conA = e.c * det_inv, conB = -e.b * det_inv, conC = e.a * det_inv;
+            const float mid = 0.5f * (e.a + e.c);
+            float disc = mid * mid - det;
+            if (disc < GSR_LAMBDA_FLOOR) disc = GSR_LAMBDA_FLOOR;
+            const float l1 = mid + sqrtf(disc), l2 = mid - sqrtf(disc);
+            const float lmax = l1 > l2 ? l1 : l2;
+            const int radius = (int)ceilf(GSR_SIGMA_EXTENT * sqrtf(lmax));
+            const float px = ((ndcx + 1.f) * (float)a.W - 1.f) * 0.5f;             // S5
+            const float py = ((ndcy + 1.f) * (float)a.H - 1.f) * 0.5f;
+            int x0, y0, x1, y1;
+            tile_rect(px, py, radius, a.gridx, a.gridy, x0, y0, x1, y1);
+            const int area = (x1 - x0) * (y1 - y0);
+            if (area != 0) {
+                float rgb[3];
+                if (a.colors_precomp) {
+                    rgb[0] = a.colors_precomp[3 * si]; rgb[1] = a.colors_precomp[3 * si + 1]; rgb[2] = a.colors_precomp[3 * si + 2];
+                } else {                                                            // S6
+                    float dir[3] = {p[0] - a.campos[0], p[1] - a.campos[1], p[2] - a.campos[2]};
+                    const float il = 1.f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+                    dir[0] *= il; dir[1] *= il; dir[2] *= il;
+                    float b[16];
+                    sh_basis<D>(dir, b);
+                    constexpr int K = (D + 1) * (D + 1);
+                    float c[3 * K + 3];
+                    load_sh_row<K>(a.shs, si, a.M, c);
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int k = 0; k < K; k++) v += b[k] * c[k * 3 + ch];
+                        v += 0.5f;
+                        if (v < 0.f) clamp_out |= (uint8_t)(1u << ch);
+                        rgb[ch] = v < 0.f ? 0.f : v;
+                    }
+                }
+                radius_out = radius;
+                tiles_out = (uint32_t)area;
+                depth_out = pv[2];
+                rect_out = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
+                r0 = make_float4(px, py, conA, conB);
+                r1 = make_float4(conC, a.opacities[si], rgb[0], rgb[1]);
+                r2 = make_float4(rgb[2], pv[2], 0.f, 0.f);
+            }
+        }
+    }
+    float4 *rec = reinterpret_cast<float4 *>(a.g.rec) + 3 * si;
+    rec[0] = r0; rec[1] = r1; rec[2] = r2;
+    a.g.depth[si] = depth_out;
+    a.g.rect[si] = rect_out;
+    a.g.tiles[si] = tiles_out;
+    a.g.clamped[si] = clamp_out;
+    a.radii[si] = radius_out;
+}
+
+hipError_t launch_preprocess_fwd(const PreprocessArgs &a, hipStream_t s) {
+    if (a.P <= 0) return hipSuccess;
+    const dim3 grid((a.P + 255) / 256), block(256);
+    switch (a.shs ? a.D : 0) {
+        case 0: hipLaunchKernelGGL(preprocess_fwd_kernel<0>, grid, block, 0, s, a); break;
+        case 1: hipLaunchKernelGGL(preprocess_fwd_kernel<1>, grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL(preprocess_fwd_kernel<2>, grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL(preprocess_fwd_kernel<3>, grid, block, 0, s, a); break;
+    }
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float *__restrict__ means3D,
+                                                           const float *__restrict__ V, uint8_t *__restrict__ present) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float p[3] = {means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]};
+    float pv[3];
+    xform4x3(V, p, pv);
+    present[i] = pv[2] > GSR_NEAR_Z ? 1 : 0;
+}
+
+hipError_t launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s) {
+    if (P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, viewmatrix, present);
+    return hipGetLastError();
+}
+
+}  // namespace gsr

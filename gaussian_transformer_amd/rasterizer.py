@@ -1,0 +1,253 @@
+"""GaussianRasterizationSettings / GaussianRasterizer: the reference's rasterizer API on HIP.
+
+Drop-in for the names the reference imports at gaussian_renderer/__init__.py:14 and uses at
+:36-49 (settings), :51 (constructor), :85-93 (keyword-only forward returning (color, radii)).
+Same field order, argument meaning, validation messages and gradient order as the absent
+upstream package; the native layer underneath is libgsr_hip.so through ctypes
+(_lib.py) instead of pybind11/CUDA.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None or t.numel() == 0 else t.data_ptr()
+
+
+def _f32c(t: torch.Tensor, name: str, device) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise _lib.GsrError(f"{name} must be float32, got {t.dtype}")
+    if t.device != device:
+        t = t.to(device)
+    return t.contiguous()
+
+
+class HipBackend:
+    """Calls the C ABI.  The only backend the product ever constructs."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self._ws_cache = {}
+
+    def _sizes(self, P, W, H):
+        key = (P, W, H)
+        v = self._ws_cache.get(key)
+        if v is None:
+            g, i, b = C.c_size_t(), C.c_size_t(), C.c_size_t()
+            _lib.check(self.lib.gsr_workspace_sizes(P, W, H, C.byref(g), C.byref(i), C.byref(b)), "gsr_workspace_sizes")
+            v = (g.value, i.value, b.value)
+            if len(self._ws_cache) > 64:
+                self._ws_cache.clear()
+            self._ws_cache[key] = v
+        return v
+
+    def forward(self, rs: GaussianRasterizationSettings, means3D, shs, colors_precomp, opacities, scales, rotations,
+                cov3D_precomp):
+        dev = means3D.device
+        if dev.type != "cuda":
+            raise _lib.GsrError(f"the HIP rasterizer needs tensors on a HIP device, got {dev} (no CPU fallback)")
+        P, H, W = int(means3D.shape[0]), int(rs.image_height), int(rs.image_width)
+        M = int(shs.shape[1]) if shs.numel() else 0
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            gb, ib, _ = self._sizes(P, W, H)
+            u8 = dict(dtype=torch.uint8, device=dev)
+            color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+            radii = torch.empty((P,), dtype=torch.int32, device=dev)
+            geom = torch.empty((gb,), **u8)
+            img = torch.empty((ib,), **u8)
+            holder = []
+
+            def alloc(_user, nbytes):
+                try:
+                    t = torch.empty((max(int(nbytes), 1),), **u8)
+                    holder.append(t)
+                    return t.data_ptr()
+                except Exception:        # allocation failure surfaces as GSR_ERR_ALLOC
+                    return None
+            cb = _lib.ALLOC_FN(alloc)
+            n = C.c_int64(0)
+            bg = _f32c(rs.bg, "bg", dev); vm = _f32c(rs.viewmatrix, "viewmatrix", dev)
+            pm = _f32c(rs.projmatrix, "projmatrix", dev); cp = _f32c(rs.campos, "campos", dev)
+            rc = self.lib.gsr_forward(
+                stream, P, int(rs.sh_degree), M, W, H, _ptr(bg), _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
+                _ptr(opacities), _ptr(scales), float(rs.scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
+                _ptr(vm), _ptr(pm), _ptr(cp), float(rs.tanfovx), float(rs.tanfovy), int(bool(rs.prefiltered)),
+                int(bool(rs.debug)), color.data_ptr(), _ptr(radii), geom.data_ptr(), gb, cb, None, img.data_ptr(), ib,
+                C.byref(n))
+            _lib.check(rc, "gsr_forward")
+            binning = holder[0] if holder else torch.empty((0,), **u8)
+        return int(n.value), color, radii, geom, binning, img
+
+    def backward(self, rs, num_rendered, dL_dpix, means3D, radii, shs, colors_precomp, scales, rotations,
+                 cov3D_precomp, geom, binning, img):
+        dev = means3D.device
+        P, H, W = int(means3D.shape[0]), int(rs.image_height), int(rs.image_width)
+        M = int(shs.shape[1]) if shs.numel() else 0
+        f32 = dict(dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _, _, bb = self._sizes(P, W, H)
+            bwd_ws = torch.empty((bb,), dtype=torch.uint8, device=dev)
+            g_means2D = torch.empty((P, 3), **f32); g_opacity = torch.empty((P, 1), **f32)
+            g_colors = torch.empty((P, 3), **f32); g_means3D = torch.empty((P, 3), **f32)
+            g_cov3D = torch.empty((P, 6), **f32)
+            g_sh = torch.empty((P, M, 3), **f32) if M > 0 else torch.empty((0,), **f32)
+            has_sr = scales.numel() > 0
+            g_scales = torch.empty((P, 3), **f32) if has_sr else torch.empty((0,), **f32)
+            g_rots = torch.empty((P, 4), **f32) if has_sr else torch.empty((0,), **f32)
+            bg = _f32c(rs.bg, "bg", dev); vm = _f32c(rs.viewmatrix, "viewmatrix", dev)
+            pm = _f32c(rs.projmatrix, "projmatrix", dev); cp = _f32c(rs.campos, "campos", dev)
+            dL = _f32c(dL_dpix, "grad of rendered image", dev)
+            rc = self.lib.gsr_backward(
+                stream, P, int(rs.sh_degree), M, int(num_rendered), W, H, _ptr(bg), _ptr(means3D), _ptr(radii),
+                _ptr(shs), _ptr(colors_precomp), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
+                _ptr(cov3D_precomp), _ptr(vm), _ptr(pm), _ptr(cp), float(rs.tanfovx), float(rs.tanfovy), _ptr(dL),
+                _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(), _ptr(bwd_ws),
+                bwd_ws.numel(), _ptr(g_means2D), _ptr(g_opacity), _ptr(g_colors), _ptr(g_means3D), _ptr(g_cov3D),
+                _ptr(g_sh), _ptr(g_scales), _ptr(g_rots), int(bool(rs.debug)))
+            _lib.check(rc, "gsr_backward")
+        return g_means3D, g_means2D, g_sh, g_colors, g_opacity, g_scales, g_rots, g_cov3D
+
+    def mark_visible(self, positions, viewmatrix, projmatrix):
+        dev = positions.device
+        if dev.type != "cuda":
+            raise _lib.GsrError(f"the HIP rasterizer needs tensors on a HIP device, got {dev} (no CPU fallback)")
+        P = int(positions.shape[0])
+        out = torch.empty((P,), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            pos = _f32c(positions, "positions", dev); vm = _f32c(viewmatrix, "viewmatrix", dev)
+            pm = _f32c(projmatrix, "projmatrix", dev)
+            rc = self.lib.gsr_mark_visible(torch.cuda.current_stream(dev).cuda_stream, P, _ptr(pos), _ptr(vm), _ptr(pm), _ptr(out))
+            _lib.check(rc, "gsr_mark_visible")
+        return out.bool()
+
+
+_backend = None
+
+
+def get_backend():
+    global _backend
+    if _backend is None:
+        _backend = HipBackend()      # raises if libgsr_hip.so is missing: no fallback
+    return _backend
+
+
+def _set_backend_for_tests(backend):
+    """Test hook: tests/ inject an oracle-backed stand-in to exercise the host logic (argument
+    validation, autograd plumbing, the gloo data-parallel path) on machines without a GPU.
+    Product code never calls this."""
+    global _backend
+    prev = _backend
+    _backend = backend
+    return prev
+
+
+def _dump(path, *objs):
+    try:
+        torch.save(tuple(o.detach().cpu() if isinstance(o, torch.Tensor) else o for o in objs), path)
+    except Exception:
+        pass
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        be = get_backend()
+        dev = means3D.device
+        if means3D.dim() != 2 or means3D.shape[1] != 3:
+            raise _lib.GsrError("means3D must have dimensions (num_points, 3)")
+        args = [_f32c(t, n, dev) for t, n in ((means3D, "means3D"), (sh, "shs"), (colors_precomp, "colors_precomp"),
+                                              (opacities, "opacities"), (scales, "scales"), (rotations, "rotations"),
+                                              (cov3Ds_precomp, "cov3D_precomp"))]
+        means3D_c, sh_c, colors_c, opac_c, scales_c, rots_c, cov_c = args
+        try:
+            num_rendered, color, radii, geom, binning, img = be.forward(
+                raster_settings, means3D_c, sh_c, colors_c, opac_c, scales_c, rots_c, cov_c)
+        except Exception:
+            if raster_settings.debug:
+                _dump("snapshot_fw.dump", *args, raster_settings._asdict())
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+            raise
+        ctx.raster_settings = raster_settings
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_c, means3D_c, scales_c, rots_c, cov_c, radii, sh_c, geom, binning, img)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        be = get_backend()
+        rs = ctx.raster_settings
+        colors_c, means3D_c, scales_c, rots_c, cov_c, radii, sh_c, geom, binning, img = ctx.saved_tensors
+        try:
+            g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov = be.backward(
+                rs, ctx.num_rendered, grad_out_color, means3D_c, radii, sh_c, colors_c, scales_c, rots_c, cov_c,
+                geom, binning, img)
+        except Exception:
+            if rs.debug:
+                _dump("snapshot_bw.dump", grad_out_color, means3D_c, radii, sh_c, colors_c, scales_c, rots_c, cov_c,
+                      ctx.num_rendered, rs._asdict())
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+            raise
+        none_if_empty = lambda g, src: g if src.numel() > 0 else None
+        return (g_means3D, g_means2D, none_if_empty(g_sh, sh_c), none_if_empty(g_colors, colors_c), g_opac,
+                none_if_empty(g_scales, scales_c), none_if_empty(g_rots, rots_c), none_if_empty(g_cov, cov_c), None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    """Constructed per render call by the reference (gaussian_renderer/__init__.py:51): O(us), no allocation."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        with torch.no_grad():
+            rs = self.raster_settings
+            return get_backend().mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        empty = means3D.new_empty((0,), dtype=torch.float32)
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)

@@ -1,0 +1,129 @@
+/*
+ * gsr.h -- C ABI of the MI355X-native differentiable Gaussian rasterizer (libgsr_hip.so).
+ *
+ * This is the drop-in boundary for the one hot path of stu214634/gaussian-transformer:
+ * the native extension behind `diff_gaussian_rasterization.GaussianRasterizer`, which the
+ * reference calls at gaussian_renderer/__init__.py:14,36-49,51,85-93.  The reference's own
+ * native layer (submodules/diff-gaussian-rasterization, .gitmodules:4-6) is an empty directory
+ * in the snapshot; the entry points below are what its Python front-end binds
+ * (SURVEY.md 2b "pybind/torch glue", 8b "C ABI to export"):
+ *
+ *   gsr_forward       <->  _C.rasterize_gaussians           (RasterizeGaussiansCUDA)
+ *   gsr_backward      <->  _C.rasterize_gaussians_backward  (RasterizeGaussiansBackwardCUDA)
+ *   gsr_mark_visible  <->  _C.mark_visible                  (markVisible; unused by this reference)
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  Every pointer is a DEVICE pointer
+ *     on the current HIP device unless marked (host).  NULL means "not provided".
+ *   - all floating point data is float32; the caller owns every buffer (PyTorch's caching
+ *     allocator in the Python host); the library never frees or retains pointers across calls.
+ *   - work is enqueued on `stream` (torch's current stream).  gsr_forward synchronises the
+ *     stream once (it must read the number of (Gaussian,tile) pairs to size the binning
+ *     workspace); gsr_backward never synchronises unless debug != 0.
+ *   - return value: 0 on success, a GSR_ERR_* code otherwise; gsr_last_error() gives the text
+ *     (thread-local).  The library never aborts the process and leaves the device usable, because
+ *     callers catch RuntimeError and continue (train_stacked_transformer.py:392-398).
+ *   - matrices use the reference's memory layout (scene/cameras.py:54-57): the 16 floats of
+ *     world_view_transform / full_proj_transform as stored, i.e. x' = m[0]x + m[4]y + m[8]z + m[12].
+ */
+#ifndef GSR_H
+#define GSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_ABI_VERSION 1
+
+enum {
+    GSR_OK = 0,
+    GSR_ERR_INVALID_ARGUMENT = 1, /* bad sizes / missing or contradictory inputs            */
+    GSR_ERR_ALLOC = 2,            /* the binning allocation callback returned NULL           */
+    GSR_ERR_HIP = 3,              /* a HIP / rocPRIM call failed; text in gsr_last_error()   */
+    GSR_ERR_WORKSPACE = 4         /* a caller-provided workspace is too small                */
+};
+
+typedef void *gsr_stream_t; /* hipStream_t */
+
+/* Allocation callback for the binning workspace, whose size is only known after the
+ * per-Gaussian stage has run (upstream: the resize-callback of its BinningState).  Must return
+ * a device pointer to at least `bytes` bytes, 256-byte aligned, valid until the matching
+ * gsr_backward has been enqueued, or NULL on failure. */
+typedef void *(*gsr_alloc_fn)(void *user, size_t bytes);
+
+int32_t gsr_abi_version(void);
+const char *gsr_last_error(void);
+
+/* Sizes (bytes) of the caller-allocated workspaces:
+ *   geom_bytes : per-Gaussian state written by gsr_forward, read by gsr_backward
+ *   img_bytes  : per-tile ranges + per-pixel final transmittance / last contributor
+ *   bwd_bytes  : scratch used only inside gsr_backward (gradient accumulators) */
+int32_t gsr_workspace_sizes(int32_t P, int32_t W, int32_t H, size_t *geom_bytes, size_t *img_bytes, size_t *bwd_bytes);
+
+/* Size of the binning workspace for N (Gaussian,tile) pairs (what the callback is asked for). */
+int32_t gsr_binning_bytes(int64_t N, int32_t W, int32_t H, size_t *bytes);
+
+/* Forward: per-Gaussian projection + SH (S1-S6), scan, key emission (S7), radix sort,
+ * tile ranges (S8), front-to-back compositing (S9).
+ *   P Gaussians, D active SH degree (0..3), M stored SH coefficients per channel,
+ *   W x H image.  Exactly one of shs / colors_precomp and exactly one of
+ *   (scales, rotations) / cov3D_precomp must be non-NULL.
+ *   out_color [3,H,W], radii [P] int32 are fully written.  *num_rendered (host) receives the
+ *   number of (Gaussian,tile) pairs.  P == 0 writes a zero image (not background). */
+int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_t W, int32_t H,
+                    const float *bg /*[3]*/, const float *means3D /*[P,3]*/, const float *shs /*[P,M,3]*/,
+                    const float *colors_precomp /*[P,3]*/, const float *opacities /*[P]*/,
+                    const float *scales /*[P,3]*/, float scale_modifier, const float *rotations /*[P,4]*/,
+                    const float *cov3D_precomp /*[P,6]*/, const float *viewmatrix /*[16]*/,
+                    const float *projmatrix /*[16]*/, const float *campos /*[3]*/, float tanfovx, float tanfovy,
+                    int32_t prefiltered, int32_t debug, float *out_color /*[3,H,W]*/, int32_t *radii /*[P]*/,
+                    void *geom_ws, size_t geom_bytes, gsr_alloc_fn binning_alloc, void *binning_user,
+                    void *img_ws, size_t img_bytes, int64_t *num_rendered /*host*/);
+
+/* Backward: reverse compositing (S10) + per-Gaussian chain (S11-S13).
+ *   R = num_rendered of the matching forward; geom_ws / binning_ws / img_ws as the forward left
+ *   them (read-only here); radii as returned by the forward.
+ *   Every gradient buffer is fully written (no pre-zeroing needed):
+ *     dL_dmeans2D [P,3] (x,y = gradient w.r.t. NDC coordinates, z = 0), dL_dopacity [P],
+ *     dL_dcolors [P,3], dL_dmeans3D [P,3], dL_dcov3D [P,6],
+ *     dL_dsh [P,M,3] (NULL iff shs NULL), dL_dscales [P,3] / dL_drots [P,4] (NULL iff scales NULL). */
+int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64_t R, int32_t W, int32_t H,
+                     const float *bg, const float *means3D, const int32_t *radii, const float *shs,
+                     const float *colors_precomp, const float *scales, float scale_modifier,
+                     const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                     const float *projmatrix, const float *campos, float tanfovx, float tanfovy,
+                     const float *dL_dpix /*[3,H,W]*/, const void *geom_ws, size_t geom_bytes,
+                     const void *binning_ws, size_t binning_bytes, const void *img_ws, size_t img_bytes,
+                     void *bwd_ws, size_t bwd_bytes, float *dL_dmeans2D, float *dL_dopacity, float *dL_dcolors,
+                     float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drots,
+                     int32_t debug);
+
+/* present[i] = 1 iff Gaussian i passes the near-plane test (view z > 0.2). */
+int32_t gsr_mark_visible(gsr_stream_t stream, int32_t P, const float *means3D, const float *viewmatrix,
+                         const float *projmatrix, uint8_t *present /*[P]*/);
+
+/* Introspection for tests and the bench (device -> host copies, synchronising):
+ * copies stage outputs out of the opaque workspaces.  Any destination may be NULL. */
+int32_t gsr_debug_read_geom(gsr_stream_t stream, int32_t P, const void *geom_ws, float *depth /*[P]*/,
+                            float *xy /*[P,2]*/, float *conic_opacity /*[P,4]*/, float *rgb /*[P,3]*/,
+                            uint32_t *tiles_touched /*[P]*/, uint8_t *clamped /*[P,3]*/);
+int32_t gsr_debug_read_binning(gsr_stream_t stream, int64_t N, int32_t W, int32_t H, const void *binning_ws,
+                               const void *img_ws, uint64_t *keys_sorted /*[N]*/, uint32_t *point_list /*[N]*/,
+                               uint32_t *ranges /*[T,2]*/);
+int32_t gsr_debug_read_image_state(gsr_stream_t stream, int32_t W, int32_t H, const void *img_ws,
+                                   float *final_T /*[H,W]*/, uint32_t *n_contrib /*[H,W]*/);
+
+/* Per-stage timing of the last gsr_forward / gsr_backward on this thread, milliseconds,
+ * measured with hipEvents on `stream` when profiling was enabled by gsr_set_profiling(1).
+ * names: array of GSR_NUM_STAGES const char*; ms: array of GSR_NUM_STAGES floats (host). */
+#define GSR_NUM_STAGES 12
+int32_t gsr_set_profiling(int32_t enable);
+int32_t gsr_get_stage_times(const char **names, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H */

@@ -26,3 +26,46 @@ def grad_err(a, b):
     if a.size == 0:
         return 0.0
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+# ---------------------------------------------------------------------------------------------
+# GPU side: run the HIP path through the public API (-> ctypes -> C ABI) on a ref.Scene
+# ---------------------------------------------------------------------------------------------
+def hip_forward_backward(S, dL=None, device="cuda", debug=False):
+    """Returns dict(color, radii, grads{...}, ctx=(num_rendered, geom, binning, img)) as numpy."""
+    import torch
+    from gaussian_transformer_amd import GaussianRasterizationSettings, GaussianRasterizer
+
+    def t(a, grad=True):
+        if a is None:
+            return None
+        x = torch.tensor(np.asarray(a, dtype=np.float32), device=device)
+        return x.requires_grad_(grad)
+    P = int(np.asarray(S.means3D).shape[0])
+    inp = dict(means3D=t(np.asarray(S.means3D).reshape(P, 3)), opacities=t(np.asarray(S.opacities).reshape(P, 1)),
+               shs=t(S.shs), colors_precomp=t(S.colors_precomp), scales=t(S.scales), rotations=t(S.rotations),
+               cov3D_precomp=t(S.cov3D_precomp))
+    means2D = torch.zeros((P, 3), dtype=torch.float32, device=device, requires_grad=True)
+    rs = GaussianRasterizationSettings(
+        image_height=S.H, image_width=S.W, tanfovx=S.tanfovx, tanfovy=S.tanfovy, bg=t(S.bg, False),
+        scale_modifier=S.scale_modifier, viewmatrix=t(np.asarray(S.viewmatrix).reshape(4, 4), False),
+        projmatrix=t(np.asarray(S.projmatrix).reshape(4, 4), False), sh_degree=S.sh_degree, campos=t(S.campos, False),
+        prefiltered=False, debug=debug)
+    color, radii = GaussianRasterizer(raster_settings=rs)(means2D=means2D, **inp)
+    out = dict(color=color.detach().cpu().numpy(), radii=radii.cpu().numpy())
+    if dL is not None:
+        color.backward(torch.tensor(np.asarray(dL, dtype=np.float32), device=device))
+        g = {k: (v.grad.cpu().numpy() if v is not None and v.grad is not None else None) for k, v in inp.items()}
+        g["means2D"] = means2D.grad.cpu().numpy()
+        out["grads"] = g
+    return out
+
+
+def assert_image_close(a, b, atol=RGB_ATOL, outlier_frac=2e-4, outlier_max=6e-3):
+    """RGB parity: |a-b| <= 1e-4 everywhere except a vanishing fraction of pixels where a
+    1-ulp difference in exp() flips one of the discrete tests of S9 (alpha < 1/255 skip,
+    T < 1e-4 stop); such a flip moves a pixel by at most ~alpha_min = 1/255."""
+    d = np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))
+    bad = (d > atol).any(axis=0)
+    assert bad.mean() <= outlier_frac, f"{bad.sum()} of {bad.size} pixels differ by more than {atol} (max {d.max():.3e})"
+    assert d.max() <= outlier_max, f"max abs difference {d.max():.3e}"
