@@ -2,6 +2,7 @@
 // carving, stage sequencing on the caller's stream, error reporting.  Host code only.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -13,8 +14,9 @@
 namespace gsr {
 
 static thread_local char g_err[512] = "";
-static thread_local int g_profiling = 0;
-static thread_local float g_stage_ms[GSR_NUM_STAGES] = {0};
+// process-wide (not thread-local): PyTorch's autograd engine calls gsr_backward from its own thread
+static std::atomic<int> g_profiling{0};
+static float g_stage_ms[GSR_NUM_STAGES] = {0};
 static const char *const k_stage_names[GSR_NUM_STAGES] = {
     "fwd.preprocess", "fwd.scan", "fwd.readback_N", "fwd.emit_keys", "fwd.sort", "fwd.ranges", "fwd.composite",
     "bwd.zero_acc", "bwd.composite", "bwd.pergauss", "fwd.total", "bwd.total"};
@@ -122,7 +124,7 @@ extern "C" {
 int32_t gsr_abi_version(void) { return GSR_ABI_VERSION; }
 const char *gsr_last_error(void) { return g_err; }
 
-int32_t gsr_set_profiling(int32_t enable) { g_profiling = enable ? 1 : 0; return GSR_OK; }
+int32_t gsr_set_profiling(int32_t enable) { g_profiling.store(enable ? 1 : 0); return GSR_OK; }
 int32_t gsr_get_stage_times(const char **names, float *ms) {
     for (int i = 0; i < GSR_NUM_STAGES; i++) {
         if (names) names[i] = k_stage_names[i];
@@ -187,7 +189,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     if (img_bytes < im.total_bytes) return fail(GSR_ERR_WORKSPACE, "image workspace %zu < %zu", img_bytes, im.total_bytes);
     const int gridx = grid_dim(W), gridy = grid_dim(H), T = gridx * gridy;
 
-    StageTimer tm(s, g_profiling != 0);
+    StageTimer tm(s, g_profiling.load() != 0);
     tm.mark(0);
     PreprocessArgs pa;
     pa.P = P; pa.D = D; pa.M = M; pa.W = W; pa.H = H; pa.gridx = gridx; pa.gridy = gridy;
@@ -271,7 +273,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     if (bwd_bytes < acc_bytes) return fail(GSR_ERR_WORKSPACE, "backward workspace %zu < %zu", bwd_bytes, acc_bytes);
     const int gridx = grid_dim(W), gridy = grid_dim(H);
 
-    StageTimer tm(s, g_profiling != 0);
+    StageTimer tm(s, g_profiling.load() != 0);
     tm.mark(7);
     HIP_TRY(hipMemsetAsync(bwd_ws, 0, acc_bytes, s), "zero accumulators");
     tm.mark(8);

@@ -116,7 +116,7 @@ int32_t gsr_debug_read_binning(gsr_stream_t stream, int64_t N, int32_t W, int32_
 int32_t gsr_debug_read_image_state(gsr_stream_t stream, int32_t W, int32_t H, const void *img_ws,
                                    float *final_T /*[H,W]*/, uint32_t *n_contrib /*[H,W]*/);
 
-/* Per-stage timing of the last gsr_forward / gsr_backward on this thread, milliseconds,
+/* Per-stage timing of the last gsr_forward / gsr_backward of this process, milliseconds,
  * measured with hipEvents on `stream` when profiling was enabled by gsr_set_profiling(1).
  * names: array of GSR_NUM_STAGES const char*; ms: array of GSR_NUM_STAGES floats (host). */
 #define GSR_NUM_STAGES 12
