@@ -44,6 +44,8 @@ SIGNATURES = {
     "gsr_debug_read_geom": (_i32, [_p, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "gsr_debug_read_binning": (_i32, [_p, C.c_int64, _i32, _i32, _p, _p, _p, _p, _p]),
     "gsr_debug_read_image_state": (_i32, [_p, _i32, _i32, _p, _p, _p]),
+    "gsr_set_option": (_i32, [C.c_char_p, _i32]),
+    "gsr_get_option": (_i32, [C.c_char_p, C.POINTER(_i32)]),
     "gsr_set_profiling": (_i32, [_i32]),
     "gsr_get_stage_times": (_i32, [C.POINTER(C.c_char_p), C.POINTER(_f)]),
 }
@@ -88,3 +90,8 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().gsr_last_error()
         raise GsrError(f"{what} failed (code {rc}): {msg.decode(errors='replace') if msg else ''}")
+
+
+def set_option(name: str, value: int) -> None:
+    """Process-wide tuning knob of the native library (include/gsr.h: gsr_set_option)."""
+    check(load().gsr_set_option(name.encode(), int(value)), f"gsr_set_option({name})")

@@ -43,22 +43,38 @@ hipError_t launch_sort(const BinningView &b, int64_t N, int bits, hipStream_t s)
                                      (unsigned)bits, s, false);
 }
 
-__global__ __launch_bounds__(256) void emit_keys_kernel(int P, int gridx, const uint32_t *__restrict__ tiles,
+__global__ __launch_bounds__(256) void emit_keys_kernel(int P, int W, int H, int gridx, int exact_cull,
+                                                        const uint32_t *__restrict__ tiles,
                                                         const uint32_t *__restrict__ offsets,
-                                                        const uint2 *__restrict__ rect, const float *__restrict__ depth,
+                                                        const uint2 *__restrict__ rect, const float *__restrict__ rec,
                                                         uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     const int lane = threadIdx.x & 63;
     const int g0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
     if (g0 >= P) return;                                  // wave-uniform
     const int g = g0 + lane;
     const int gc = g < P ? g : P - 1;
-    const uint32_t wave_start = g0 > 0 ? offsets[g0 - 1] : 0u;
-    const uint32_t incl = offsets[gc] - wave_start;       // lanes past P repeat the last value
-    const uint32_t cnt = g < P ? tiles[gc] : 0u;
-    const uint32_t excl = incl - cnt;
+    const uint32_t out_start = g0 > 0 ? offsets[g0 - 1] : 0u;   // first output slot of this wave
+    const uint32_t out_total = offsets[min(g0 + 63, P - 1)] - out_start;
+    if (out_total == 0) return;                           // wave-uniform
     const uint2 rc = rect[gc];
-    const uint32_t dbits = __float_as_uint(depth[gc]);
+    const uint32_t rw = (rc.x >> 16) - (rc.x & 0xffffu), rh = (rc.y >> 16) - (rc.y & 0xffffu);
+    // candidates = tiles of the 3-sigma rectangle; splats that emit nothing are not walked at all
+    const uint32_t cand = (g < P && tiles[gc] > 0u) ? rw * rh : 0u;
+    uint32_t incl = cand;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+    const uint32_t excl = incl - cand;
     const uint32_t total = __shfl(incl, 63);
+    const float4 r0 = reinterpret_cast<const float4 *>(rec)[3 * (size_t)gc];
+    const float4 r1 = reinterpret_cast<const float4 *>(rec)[3 * (size_t)gc + 1];
+    const float4 r2 = reinterpret_cast<const float4 *>(rec)[3 * (size_t)gc + 2];
+    const uint32_t dbits = __float_as_uint(r2.y);
+    const CullParams cp = make_cull(r0.z, r0.w, r1.x, r2.z);
+    uint32_t running = 0;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
     // wave-uniform trip count: every lane stays active for the cross-lane reads
     for (uint32_t base = 0; base < total; base += 64) {
         const uint32_t j = base + lane;
@@ -72,22 +88,37 @@ __global__ __launch_bounds__(256) void emit_keys_kernel(int P, int gridx, const 
         const uint32_t e = __shfl(excl, src);
         const uint32_t rx = __shfl(rc.x, src), ry = __shfl(rc.y, src);
         const uint32_t db = __shfl(dbits, src);
-        if (j < total) {
-            const uint32_t x0 = rx & 0xffffu, w = (rx >> 16) - x0, y0 = ry & 0xffffu;
-            const uint32_t k = j - e;
-            const uint32_t ty = k / w, tx = k - ty * w;
+        const uint32_t x0 = rx & 0xffffu, x1 = rx >> 16, y0 = ry & 0xffffu;
+        const uint32_t w = max(x1 - x0, 1u);
+        const uint32_t k = j - e;
+        const uint32_t ty = k / w, tx = k - ty * w;
+        bool pass = j < total;
+        if (exact_cull) {                                 // wave-uniform
+            CullParams c;
+            c.tau = __shfl(cp.tau, src); c.xmax = __shfl(cp.xmax, src); c.ymax = __shfl(cp.ymax, src);
+            c.dy_at_xmax = __shfl(cp.dy_at_xmax, src); c.det = __shfl(cp.det, src);
+            const float px = __shfl(r0.x, src), py = __shfl(r0.y, src), A = __shfl(r0.z, src), B = __shfl(r0.w, src);
+            int c0, c1;
+            tile_row_span(c, px, py, A, B, (int)(y0 + ty), W, H, (int)x0, (int)x1, c0, c1);
+            pass = pass && ((int)(x0 + tx) >= c0) && ((int)(x0 + tx) < c1);
+        }
+        const uint64_t ballot = __ballot(pass);
+        const uint32_t slot = running + (uint32_t)__popcll(ballot & lt_mask);
+        if (pass && slot < out_total) {                   // slot < out_total always holds (same span function as the count)
             const uint32_t tile = (y0 + ty) * (uint32_t)gridx + (x0 + tx);
-            const size_t o = (size_t)wave_start + j;
+            const size_t o = (size_t)out_start + slot;
             keys[o] = ((uint64_t)tile << 32) | db;
             vals[o] = (uint32_t)(g0 + src);
         }
+        running += (uint32_t)__popcll(ballot);
     }
 }
 
-hipError_t launch_emit_keys(const GeomView &g, const BinningView &b, int P, int gridx, hipStream_t s) {
+hipError_t launch_emit_keys(const GeomView &g, const BinningView &b, int P, int W, int H, int exact_cull, hipStream_t s) {
     if (P <= 0) return hipSuccess;
-    hipLaunchKernelGGL(emit_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, gridx, g.tiles, g.offsets, g.rect,
-                       g.depth, b.keys_unsorted, b.point_list_unsorted);
+    const int gridx = (W + GSR_TILE - 1) / GSR_TILE;
+    hipLaunchKernelGGL(emit_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, W, H, gridx, exact_cull, g.tiles,
+                       g.offsets, g.rect, g.rec, b.keys_unsorted, b.point_list_unsorted);
     return hipGetLastError();
 }
 

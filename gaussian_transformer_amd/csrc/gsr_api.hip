@@ -16,6 +16,7 @@ namespace gsr {
 static thread_local char g_err[512] = "";
 // process-wide (not thread-local): PyTorch's autograd engine calls gsr_backward from its own thread
 static std::atomic<int> g_profiling{0};
+static std::atomic<int> g_exact_cull{1};   // output-invariant exact splat-vs-tile culling (gsr_set_option)
 static float g_stage_ms[GSR_NUM_STAGES] = {0};
 static const char *const k_stage_names[GSR_NUM_STAGES] = {
     "fwd.preprocess", "fwd.scan", "fwd.readback_N", "fwd.emit_keys", "fwd.sort", "fwd.ranges", "fwd.composite",
@@ -124,6 +125,15 @@ extern "C" {
 int32_t gsr_abi_version(void) { return GSR_ABI_VERSION; }
 const char *gsr_last_error(void) { return g_err; }
 
+int32_t gsr_set_option(const char *name, int32_t value) {
+    if (name && !strcmp(name, "exact_tile_cull")) { g_exact_cull.store(value ? 1 : 0); return GSR_OK; }
+    return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_set_option: unknown option '%s'", name ? name : "(null)");
+}
+int32_t gsr_get_option(const char *name, int32_t *value) {
+    if (name && value && !strcmp(name, "exact_tile_cull")) { *value = g_exact_cull.load(); return GSR_OK; }
+    return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_get_option: unknown option '%s'", name ? name : "(null)");
+}
+
 int32_t gsr_set_profiling(int32_t enable) { g_profiling.store(enable ? 1 : 0); return GSR_OK; }
 int32_t gsr_get_stage_times(const char **names, float *ms) {
     for (int i = 0; i < GSR_NUM_STAGES; i++) {
@@ -196,7 +206,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     pa.means3D = means3D; pa.shs = shs; pa.colors_precomp = colors_precomp; pa.opacities = opacities;
     pa.scales = scales; pa.rotations = rotations; pa.cov3D_precomp = cov3D_precomp;
     pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.campos = campos;
-    pa.scale_modifier = scale_modifier; pa.tanfovx = tanfovx; pa.tanfovy = tanfovy; pa.radii = radii; pa.g = g;
+    pa.scale_modifier = scale_modifier; pa.tanfovx = tanfovx; pa.tanfovy = tanfovy; pa.radii = radii; pa.exact_cull = g_exact_cull.load(); pa.g = g;
     HIP_TRY(launch_preprocess_fwd(pa, s), "preprocess launch");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "preprocess");
     tm.mark(1);
@@ -218,7 +228,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     b = carve_binning(bin_ptr, N, sort_tb);
     tm.mark(3);
     if (N > 0) {
-        HIP_TRY(launch_emit_keys(g, b, P, gridx, s), "emit keys launch");
+        HIP_TRY(launch_emit_keys(g, b, P, W, H, pa.exact_cull, s), "emit keys launch");
         if (debug) HIP_TRY(hipStreamSynchronize(s), "emit keys");
         tm.mark(4);
         HIP_TRY(launch_sort(b, N, bits, s), "radix sort");

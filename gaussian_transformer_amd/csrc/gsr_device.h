@@ -196,6 +196,62 @@ __device__ __forceinline__ void tile_rect(float px, float py, int radius, int gr
     y1 = clampi_from_float((py + r + (float)(GSR_TILE - 1)) / (float)GSR_TILE, gridy);
 }
 
+// ---- exact (conservative) splat-vs-tile-row intersection ------------------------------------
+// A (Gaussian, tile) pair can only ever be blended if some pixel of the tile has
+// alpha = o*exp(-q/2) >= 1/255, i.e. q(d) = A dx^2 + 2B dx dy + C dy^2 <= tau = 2 ln(255 o).
+// Upstream enumerates every tile of the 3-sigma bounding SQUARE; pairs outside the ellipse
+// {q <= tau} are dead weight for the sort and the compositing passes (45 % of them on the headline
+// config) and dropping them changes no output: every pixel would skip them at the alpha test.
+// The tile set stays a subset of upstream's rectangle.  tau carries a safety margin so that
+// float rounding in the compositing kernels can never resurrect a dropped pair.
+struct CullParams {          // per Gaussian
+    float tau;               // inflated threshold on q; <= 0: the splat can never reach alpha_min
+    float xmax;              // half extent of {q<=tau} in x
+    float ymax;              // half extent in y
+    float dy_at_xmax;        // dy of the ellipse point with dx = +xmax
+    float det;               // A*C - B*B of the conic
+};
+#define GSR_CULL_EPS_PX 0.01f
+__device__ __forceinline__ float cull_tau(float opacity) {
+    // 2 ln(255 o) with margin; o <= 0 or NaN -> -1 (never visible)
+    if (!(opacity > 0.f)) return -1.f;
+    const float t = 2.f * logf(255.f * opacity);
+    return t > 0.f ? t * 1.0001f + 0.01f : -1.f;
+}
+__device__ __forceinline__ CullParams make_cull(float A, float B, float C, float tau) {
+    CullParams c;
+    c.tau = tau;
+    c.det = A * C - B * B;
+    const float inv = 1.f / c.det;
+    c.xmax = sqrtf(fmaxf(tau * C * inv, 0.f));
+    c.ymax = sqrtf(fmaxf(tau * A * inv, 0.f));
+    c.dy_at_xmax = -(B / C) * c.xmax;
+    return c;
+}
+// columns [c0, c1) of tile row ty (inside the rectangle columns [rx0, rx1)) that the ellipse can reach
+__device__ __forceinline__ void tile_row_span(const CullParams &c, float px, float py, float A, float B, int ty,
+                                              int W, int H, int rx0, int rx1, int &c0, int &c1) {
+    c0 = rx0; c1 = rx0;                                     // empty
+    if (!(c.tau > 0.f) || !(c.det > 0.f)) return;
+    const float ya = (float)(ty * GSR_TILE);
+    const float yb = (float)min(ty * GSR_TILE + GSR_TILE - 1, H - 1);
+    const float e0 = fmaxf(py - yb, -c.ymax), e1 = fminf(py - ya, c.ymax);   // dy = py - y over the band
+    if (!(e0 <= e1)) return;
+    const float s0 = sqrtf(fmaxf(c.tau * A - c.det * e0 * e0, 0.f));
+    const float s1 = sqrtf(fmaxf(c.tau * A - c.det * e1 * e1, 0.f));
+    const float invA = 1.f / A;
+    float dxhi, dxlo;
+    if (c.dy_at_xmax >= e0 && c.dy_at_xmax <= e1) dxhi = c.xmax;
+    else dxhi = fmaxf((-B * e0 + s0) * invA, (-B * e1 + s1) * invA);
+    if (-c.dy_at_xmax >= e0 && -c.dy_at_xmax <= e1) dxlo = -c.xmax;
+    else dxlo = fminf((-B * e0 - s0) * invA, (-B * e1 - s1) * invA);
+    const float xl = ceilf(px - dxhi - GSR_CULL_EPS_PX), xr = floorf(px - dxlo + GSR_CULL_EPS_PX);   // dx = px - x
+    const float xlc = fmaxf(xl, 0.f), xrc = fminf(xr, (float)(W - 1));
+    if (!(xlc <= xrc)) return;
+    const int t0 = max(rx0, ((int)xlc) >> 4), t1 = min(rx1, (((int)xrc) >> 4) + 1);
+    if (t1 > t0) { c0 = t0; c1 = t1; }
+}
+
 // Load the first 3*K floats of one Gaussian's SH row [M,3] into c[].  16-byte vector loads when
 // the row stride keeps every row 16-byte aligned (M = 4, 8, 12, 16 ...), scalar loads otherwise.
 template <int K>

@@ -13,7 +13,7 @@ static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a
 static inline int ceil_log2_u32(uint32_t x) { int b = 0; while ((1u << b) < x && b < 31) b++; return b; }
 
 // Per-Gaussian record gathered by the compositing kernels: 12 floats = 3 x float4.
-//   [0] px  [1] py  [2] conic.xx  [3] conic.xy | [4] conic.yy [5] opacity [6] r [7] g | [8] b [9] depth [10..11] -
+//   [0] px  [1] py  [2] conic.xx  [3] conic.xy | [4] conic.yy [5] opacity [6] r [7] g | [8] b [9] depth [10] cull tau [11] -
 #define GSR_REC_FLOATS 12
 // Gradient accumulator of the reverse compositing pass: one 64-byte row per Gaussian so that the
 // nine atomics of one (tile, Gaussian) pair fall into a single memory-side atomic request.
@@ -24,7 +24,7 @@ struct GeomView {          // per-Gaussian state, P entries each
     float *rec;            // [P][12]
     float *depth;          // [P]
     uint2 *rect;           // [P] (x0 | x1<<16, y0 | y1<<16)
-    uint32_t *tiles;       // [P] tiles touched
+    uint32_t *tiles;       // [P] (Gaussian,tile) pairs emitted (== rect area when exact culling is off)
     uint32_t *offsets;     // [P] inclusive scan of tiles
     uint8_t *clamped;      // [P] bit ch set iff SH colour channel ch was clamped at 0
     void *scan_temp;
@@ -58,6 +58,7 @@ struct PreprocessArgs {
     const float *viewmatrix, *projmatrix, *campos;
     float scale_modifier, tanfovx, tanfovy;
     int *radii;
+    int exact_cull;
     GeomView g;
 };
 hipError_t launch_preprocess_fwd(const PreprocessArgs &a, hipStream_t s);
@@ -66,7 +67,7 @@ hipError_t scan_temp_bytes(int P, size_t *bytes);
 hipError_t launch_scan(const GeomView &g, int P, hipStream_t s);
 
 hipError_t sort_temp_bytes(int64_t N, int bits, size_t *bytes);
-hipError_t launch_emit_keys(const GeomView &g, const BinningView &b, int P, int gridx, hipStream_t s);
+hipError_t launch_emit_keys(const GeomView &g, const BinningView &b, int P, int W, int H, int exact_cull, hipStream_t s);
 hipError_t launch_sort(const BinningView &b, int64_t N, int bits, hipStream_t s);
 hipError_t launch_ranges(const BinningView &b, const ImageView &im, int64_t N, int T, hipStream_t s);
 

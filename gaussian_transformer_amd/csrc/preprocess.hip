@@ -58,6 +58,19 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreprocessArgs a) {
             tile_rect(px, py, radius, a.gridx, a.gridy, x0, y0, x1, y1);
             const int area = (x1 - x0) * (y1 - y0);
             if (area != 0) {
+                const float opacity = a.opacities[si];
+                float tau = 0.f;
+                int pairs = area;
+                if (a.exact_cull) {                      // count only the tiles the ellipse can reach
+                    tau = cull_tau(opacity);
+                    const CullParams cp = make_cull(conA, conB, conC, tau);
+                    pairs = 0;
+                    for (int ty = y0; ty < y1; ty++) {
+                        int c0, c1;
+                        tile_row_span(cp, px, py, conA, conB, ty, a.W, a.H, x0, x1, c0, c1);
+                        pairs += c1 - c0;
+                    }
+                }
                 float rgb[3];
                 if (a.colors_precomp) {
                     rgb[0] = a.colors_precomp[3 * si]; rgb[1] = a.colors_precomp[3 * si + 1]; rgb[2] = a.colors_precomp[3 * si + 2];
@@ -81,12 +94,12 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreprocessArgs a) {
                     }
                 }
                 radius_out = radius;
-                tiles_out = (uint32_t)area;
+                tiles_out = (uint32_t)pairs;
                 depth_out = pv[2];
                 rect_out = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
                 r0 = make_float4(px, py, conA, conB);
-                r1 = make_float4(conC, a.opacities[si], rgb[0], rgb[1]);
-                r2 = make_float4(rgb[2], pv[2], 0.f, 0.f);
+                r1 = make_float4(conC, opacity, rgb[0], rgb[1]);
+                r2 = make_float4(rgb[2], pv[2], tau, 0.f);
             }
         }
     }

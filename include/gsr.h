@@ -116,6 +116,14 @@ int32_t gsr_debug_read_binning(gsr_stream_t stream, int64_t N, int32_t W, int32_
 int32_t gsr_debug_read_image_state(gsr_stream_t stream, int32_t W, int32_t H, const void *img_ws,
                                    float *final_T /*[H,W]*/, uint32_t *n_contrib /*[H,W]*/);
 
+/* Tuning knobs (process-wide).  Known options:
+ *   "exact_tile_cull" (default 1): emit a (Gaussian,tile) pair only if the ellipse
+ *        {alpha >= 1/255} can reach a pixel of the tile, instead of every tile of upstream's
+ *        3-sigma bounding square.  Output-invariant (dropped pairs are skipped by every pixel's
+ *        alpha test anyway); num_rendered and the internal lists shrink.  0 = upstream's rule. */
+int32_t gsr_set_option(const char *name, int32_t value);
+int32_t gsr_get_option(const char *name, int32_t *value);
+
 /* Per-stage timing of the last gsr_forward / gsr_backward of this process, milliseconds,
  * measured with hipEvents on `stream` when profiling was enabled by gsr_set_profiling(1).
  * names: array of GSR_NUM_STAGES const char*; ms: array of GSR_NUM_STAGES floats (host). */

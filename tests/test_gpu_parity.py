@@ -44,12 +44,21 @@ def _stage_dump(S):
                 final_T=fT, n_contrib=nc, **d)
 
 
+@pytest.fixture
+def upstream_tile_rule():
+    """Switch the exact tile culling off: the pair lists must then equal upstream's rule bit for bit."""
+    from gaussian_transformer_amd import _lib
+    _lib.set_option("exact_tile_cull", 0)
+    yield
+    _lib.set_option("exact_tile_cull", 1)
+
+
 @pytest.mark.parametrize("kw", [
     dict(P=3000, width=160, height=112, sh_degree=3, s0=0.03, seed=0),
     dict(P=1500, width=100, height=57, sh_degree=1, s0=0.06, seed=1, zmin=0.05, zmax=5.0),   # culled splats, ragged tiles
     dict(P=500, width=33, height=47, sh_degree=0, s0=0.5, seed=2),                            # huge splats: every tile
 ])
-def test_stages_bit_exact_against_oracle(kw):
+def test_stages_bit_exact_against_oracle(kw, upstream_tile_rule):
     sc = synth.make_scene(**kw)
     S = oracle_scene(sc, scale_modifier=1.0)
     f = ref.get("f32").forward(S)
@@ -73,6 +82,47 @@ def test_stages_bit_exact_against_oracle(kw):
     assert_image_close(h["color"], f["color"])
     assert np.abs(h["final_T"] - oi["final_T"]).max() < 1e-4 or (np.abs(h["final_T"] - oi["final_T"]) > 1e-4).mean() < 2e-4
     assert (h["n_contrib"] != oi["n_contrib"]).mean() < 1e-3
+
+
+@pytest.mark.parametrize("kw", [
+    dict(P=3000, width=160, height=112, sh_degree=3, s0=0.03, seed=0),
+    dict(P=1500, width=100, height=57, sh_degree=1, s0=0.06, seed=1, zmin=0.05, zmax=5.0),
+    dict(P=500, width=33, height=47, sh_degree=0, s0=0.5, seed=2),
+    dict(P=2000, width=256, height=144, sh_degree=0, s0=0.02, seed=3),
+])
+def test_exact_tile_culling_keeps_every_pair_a_pixel_can_blend(kw):
+    """Default mode: the emitted list must be a subsequence of upstream's list (same order) that still
+    contains every (tile, Gaussian) pair for which some pixel of the tile passes upstream's tests
+    (power <= 0 and alpha >= 1/255); then no output can change."""
+    sc = synth.make_scene(**kw)
+    S = oracle_scene(sc)
+    f = ref.get("f32").forward(S)
+    og, ob = f["state"].geom(), f["state"].binning()
+    h = _stage_dump(S)
+    np.testing.assert_array_equal(h["radii"], f["radii"])            # radii keep upstream's meaning
+    assert h["n"] <= f["num_rendered"]
+    gridx = (S.W + 15) // 16
+    xy, co = og["xy"].astype(np.float64), og["conic_o"].astype(np.float64)
+    kept = 0
+    for t in range(ob["ranges"].shape[0]):
+        full = ob["vals"][ob["ranges"][t, 0]:ob["ranges"][t, 1]]
+        mine = h["point_list"][h["ranges"][t, 0]:h["ranges"][t, 1]]
+        pos = {int(g): i for i, g in enumerate(full)}
+        idx = [pos[int(g)] for g in mine]                              # KeyError = pair not in upstream's list
+        assert idx == sorted(idx) and len(set(idx)) == len(idx)        # subsequence, same depth order
+        if len(full) == 0:
+            continue
+        tx, ty = t % gridx, t // gridx
+        xs = np.arange(tx * 16, min(tx * 16 + 16, S.W)); ys = np.arange(ty * 16, min(ty * 16 + 16, S.H))
+        X, Y = np.meshgrid(xs, ys)
+        dx = xy[full, 0][:, None, None] - X[None]; dy = xy[full, 1][:, None, None] - Y[None]
+        power = -0.5 * (co[full, 0][:, None, None] * dx * dx + co[full, 2][:, None, None] * dy * dy) - co[full, 1][:, None, None] * dx * dy
+        alpha = np.minimum(0.99, co[full, 3][:, None, None] * np.exp(power))
+        needed = ((power <= 0) & (alpha >= 1.0 / 255.0)).any(axis=(1, 2))
+        assert set(full[needed].tolist()) <= set(mine.tolist()), f"tile {t}: a blendable pair was culled"
+        kept += len(mine)
+    assert kept == h["n"]
+    assert_image_close(h["color"], f["color"])
 
 
 CASES = [
