@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--config", default="cfg3_synth_1M_1080p")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], help="native tuning knob name=value (include/gsr.h gsr_set_option)")
     args = ap.parse_args()
 
     import torch
@@ -73,6 +74,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    for kv in args.opt:
+        k, v = kv.split("=")
+        _lib.set_option(k, int(v))
     sc = synth.make_config(args.config, seed=0)
     cam_np = sc.camera
     if world > 1:   # one camera per rank: same intrinsics, camera yawed by a rank-dependent angle about the cloud's centre

@@ -1,13 +1,21 @@
 // composite_bwd.hip -- reverse compositing (S10): per pixel back-to-front over the tile's
 // depth-sorted splat list, producing dL/d{rgb, mean2D, conic, opacity} per Gaussian.
 //
-// CDNA4 shape (v1): same decomposition as the forward -- four independent wave64s per 16x16
-// tile, one per 8x8 quadrant, wave-private LDS staging, no workgroup barrier.  All 64 lanes of a
-// wave visit the same splat at the same step, so the nine partial gradients are reduced across
-// the wave in registers (DPP quad_perm / row_half_mirror / row_mirror inside each 16-lane row,
-// then two cross-row exchanges) and leave as ONE 9-lane global_atomic_add_f32 into the splat's
-// 64-byte accumulator row: one memory-side atomic request per (quadrant, splat) instead of
-// 9 x 64.  Splats that no pixel of the quadrant blends are skipped before the reduction.
+// CDNA4 shape.  A wave64 owns NPX 8x8 pixel blocks of one 16x16 tile (NPX = 4: the whole tile,
+// 2: its upper or lower half, 1: one quadrant); lane l holds pixel l of each block, so per-splat
+// work that does not depend on the pixel (LDS record read, loop control, the cross-lane gradient
+// reduction, the atomic) is paid once per NPX*64 pixels.  Waves never synchronise with each other
+// (no workgroup barrier): each stages the tile's splat list 64 records at a time into a
+// wave-private LDS slice, one record gathered per lane.  While staging, the lane also decides,
+// per 8x8 block, whether the splat can reach alpha >= 1/255 anywhere in the block (exact min of
+// the quadratic form over the block rectangle against the culling threshold of gsr_device.h); the
+// wave then walks only the set bits of the 64-bit ballot, so dead splats cost two scalar
+// instructions, and dead blocks of a live splat are skipped by a scalar branch.
+// All lanes visit the same splat at the same step, so the nine partial gradients are summed in
+// registers: v_permlane32_swap / v_permlane16_swap fold value PAIRS across the wave halves and
+// rows in two instructions per fold (keep-one/send-one, no select), four DPP steps finish the
+// 16-lane rows, and the nine totals leave as ONE global_atomic_add_f32 instruction (9 lanes) into
+// the splat's 64-byte accumulator row: one memory-side request per (wave, splat).
 #include "gsr_device.h"
 #include "gsr_internal.h"
 
@@ -15,7 +23,7 @@ namespace gsr {
 
 #define LOG2E 1.4426950408889634f
 
-__device__ __forceinline__ int xcd_band_tile_b(int b, int nblocks_padded) {
+__device__ __forceinline__ int xcd_band_unit(int b, int nblocks_padded) {
     const int chunk = nblocks_padded >> 3;
     return (b & 7) * chunk + (b >> 3);
 }
@@ -33,106 +41,182 @@ __device__ __forceinline__ float row_allreduce(float v) {
     v = dpp_add<0x140>(v);  // row_mirror
     return v;
 }
+// lanes 0-31: a[l] + a[l+32];  lanes 32-63: b[l-32] + b[l]
+__device__ __forceinline__ float fold32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// row0: a.r0 + a.r1;  row1: b.r0 + b.r1;  row2: a.r2 + a.r3;  row3: b.r2 + b.r3
+__device__ __forceinline__ float fold16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
-__global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, int nblocks_padded) {
+// exact minimum of q(d) = A dx^2 + 2 B dx dy + C dy^2 over the pixel rectangle [xa,xb] x [ya,yb]
+// (d = splat centre - pixel); compared with the splat's culling threshold tau
+__device__ __forceinline__ bool block_reachable(float px, float py, float A, float B, float C, float invA, float invC,
+                                                float tau, float xa, float xb, float ya, float yb) {
+    const float dxa = px - xa, dxb = px - xb, dya = py - ya, dyb = py - yb;   // dxb <= dx <= dxa, dyb <= dy <= dya
+    if (dxb <= 0.f && dxa >= 0.f && dyb <= 0.f && dya >= 0.f) return tau > 0.f;   // centre inside the block
+    float q;
+    {
+        float dy = fminf(fmaxf(-B * dxa * invC, dyb), dya);
+        q = (A * dxa + 2.f * B * dy) * dxa + C * dy * dy;
+        dy = fminf(fmaxf(-B * dxb * invC, dyb), dya);
+        q = fminf(q, (A * dxb + 2.f * B * dy) * dxb + C * dy * dy);
+        float dx = fminf(fmaxf(-B * dya * invA, dxb), dxa);
+        q = fminf(q, (A * dx + 2.f * B * dya) * dx + C * dya * dya);
+        dx = fminf(fmaxf(-B * dyb * invA, dxb), dxa);
+        q = fminf(q, (A * dx + 2.f * B * dyb) * dx + C * dyb * dyb);
+    }
+    return q <= tau;
+}
+
+template <int NPX>
+__global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, int nblocks_padded, int exact_cull) {
+    constexpr int UNITS_PER_TILE = 4 / NPX;          // waves per tile
     __shared__ float4 stage[4][64 * 3];
-    __shared__ uint32_t stage_id[4][64];
     const int T = a.gridx * a.gridy;
-    const int tile = xcd_band_tile_b(blockIdx.x, nblocks_padded);
-    if (tile >= T) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int unit = xcd_band_unit(blockIdx.x, nblocks_padded) * 4 + wave;
+    const int tile = unit / UNITS_PER_TILE, sub = unit % UNITS_PER_TILE;
+    if (tile >= T) return;                            // wave-uniform
     const int tx = tile % a.gridx, ty = tile / a.gridx;
-    const int x = tx * GSR_TILE + (wave & 1) * 8 + (lane & 7);
-    const int y = ty * GSR_TILE + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = x < a.W && y < a.H;
-    const float fx = (float)x, fy = (float)y;
-    const uint2 range = a.ranges[tile];
     float4 *my = stage[wave];
-    uint32_t *my_id = stage_id[wave];
     const float4 *rec4 = reinterpret_cast<const float4 *>(a.rec);
-    const size_t pix = (size_t)(inside ? y : 0) * a.W + (inside ? x : 0), HW = (size_t)a.W * a.H;
-
-    const float Tfinal = inside ? a.final_T[pix] : 1.f;
-    const int last = inside ? (int)a.n_contrib[pix] : 0;
-    const float d0 = inside ? a.dL_dpix[pix] : 0.f, d1 = inside ? a.dL_dpix[HW + pix] : 0.f,
-                d2 = inside ? a.dL_dpix[2 * HW + pix] : 0.f;
-    const float bg_dot = a.bg[0] * d0 + a.bg[1] * d1 + a.bg[2] * d2;
+    const uint2 range = a.ranges[tile];
+    const size_t HW = (size_t)a.W * a.H;
     const float halfW = 0.5f * (float)a.W, halfH = 0.5f * (float)a.H;
+    const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 
-    int max_last = last;
+    // per-pixel state, one pixel per 8x8 block q
+    float fx[NPX], fy[NPX], Tr[NPX], acc0[NPX], acc1[NPX], acc2[NPX], la[NPX], lc0[NPX], lc1[NPX], lc2[NPX];
+    float d0[NPX], d1[NPX], d2[NPX], tb[NPX];
+    int last[NPX];
+    float bxa[NPX], bya[NPX], bxb[NPX], byb[NPX];     // block rectangles (wave-uniform)
+    int max_last = 0;
+#pragma unroll
+    for (int q = 0; q < NPX; q++) {
+        const int blk = NPX == 4 ? q : (NPX == 2 ? sub * 2 + q : sub);      // 0..3: (bx = blk&1, by = blk>>1)
+        const int x0 = tx * GSR_TILE + (blk & 1) * 8, y0 = ty * GSR_TILE + (blk >> 1) * 8;
+        const int x = x0 + (lane & 7), y = y0 + (lane >> 3);
+        const bool inside = x < a.W && y < a.H;
+        const size_t pix = (size_t)(inside ? y : 0) * a.W + (inside ? x : 0);
+        fx[q] = (float)x; fy[q] = (float)y;
+        bxa[q] = (float)x0; bya[q] = (float)y0;
+        bxb[q] = (float)min(x0 + 7, a.W - 1); byb[q] = (float)min(y0 + 7, a.H - 1);
+        const float Tf = inside ? a.final_T[pix] : 1.f;
+        last[q] = inside ? (int)a.n_contrib[pix] : 0;
+        d0[q] = inside ? a.dL_dpix[pix] : 0.f;
+        d1[q] = inside ? a.dL_dpix[HW + pix] : 0.f;
+        d2[q] = inside ? a.dL_dpix[2 * HW + pix] : 0.f;
+        tb[q] = Tf * (bg0 * d0[q] + bg1 * d1[q] + bg2 * d2[q]);
+        Tr[q] = Tf; acc0[q] = acc1[q] = acc2[q] = 0.f; la[q] = 0.f; lc0[q] = lc1[q] = lc2[q] = 0.f;
+        max_last = max(max_last, last[q]);
+    }
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) max_last = max(max_last, __shfl_xor(max_last, m));
-    if (max_last == 0) return;   // wave-uniform
+    if (max_last == 0) return;                        // wave-uniform
 
-    float Tr = Tfinal, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
-    const int k16 = lane & 15;
+    // which accumulator slot this lane's reduced value belongs to (see the fold order below)
+    //   x0 rows -> (v0, v2, v1, v3) in lanes 16r,  x1 rows -> (v4, v6, v5, v7) in lanes 16r+1,  x2 row 0 -> v8 in lane 2
+    const int row = lane >> 4, k16 = lane & 15;
+    const int rowperm = ((row & 1) << 1) | (row >> 1);          // 0,2,1,3
+    int slot = -1;
+    if (k16 == 0) slot = rowperm;
+    else if (k16 == 1) slot = 4 + rowperm;
+    else if (lane == 2) slot = 8;
 
     for (int base = ((max_last - 1) >> 6) << 6; base >= 0; base -= 64) {
         const int cnt = min(64, max_last - base);
         __builtin_amdgcn_wave_barrier();
+        bool live = false;
         if (lane < cnt) {
             const uint32_t g = a.point_list[range.x + base + lane];
-            my[lane * 3 + 0] = rec4[3 * (size_t)g];
-            my[lane * 3 + 1] = rec4[3 * (size_t)g + 1];
-            my[lane * 3 + 2] = make_float4(a.rec[GSR_REC_FLOATS * (size_t)g + 8], 0.f, 0.f, 0.f);
-            my_id[lane] = g;
+            const float4 r0 = rec4[3 * (size_t)g], r1 = rec4[3 * (size_t)g + 1], r2 = rec4[3 * (size_t)g + 2];
+            uint32_t bits = (1u << NPX) - 1u;
+            if (exact_cull && r2.z > 0.f) {     // tau == 0: the forward ran with culling off -> no information
+                const float invA = 1.f / r0.z, invC = 1.f / r1.x;
+                bits = 0u;
+#pragma unroll
+                for (int q = 0; q < NPX; q++)
+                    bits |= block_reachable(r0.x, r0.y, r0.z, r0.w, r1.x, invA, invC, r2.z, bxa[q], bxb[q], bya[q], byb[q]) ? (1u << q) : 0u;
+            }
+            live = bits != 0u;
+            my[lane * 3 + 0] = r0; my[lane * 3 + 1] = r1;
+            my[lane * 3 + 2] = make_float4(r2.x, 0.f, __uint_as_float(bits), __uint_as_float(g));
         }
+        uint64_t todo = __ballot(live);
         __builtin_amdgcn_wave_barrier();
-        for (int j = cnt - 1; j >= 0; j--) {
-            const float4 r0 = my[j * 3 + 0], r1 = my[j * 3 + 1];
-            const float cb = reinterpret_cast<const float *>(my)[j * 12 + 8];
-            const float dx = r0.x - fx, dy = r0.y - fy;
-            const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
-            const float G = __builtin_amdgcn_exp2f(power * LOG2E);
-            const float alpha = fminf(GSR_ALPHA_MAX, r1.y * G);
-            const bool ok = (base + j < last) && !(power > 0.f) && !(alpha < GSR_ALPHA_MIN);
-            if (!__any(ok)) continue;                       // wave-uniform skip
-            const float one_m = 1.f - alpha;
-            const float inv = __builtin_amdgcn_rcpf(one_m);
-            const float Tk = ok ? Tr * inv : Tr;            // transmittance in front of this splat
-            // colour accumulated behind this splat
-            const float n0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-            const float n1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-            const float n2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-            float dL_dalpha = (r1.z - n0) * d0 + (r1.w - n1) * d1 + (cb - n2) * d2;
-            dL_dalpha = dL_dalpha * Tk - Tfinal * inv * bg_dot;
-            dL_dalpha = ok ? dL_dalpha : 0.f;
-            const float w = ok ? alpha * Tk : 0.f;
-            if (ok) { acc0 = n0; acc1 = n1; acc2 = n2; lc0 = r1.z; lc1 = r1.w; lc2 = cb; last_alpha = alpha; }
-            Tr = Tk;
-            const float dL_dG = r1.y * dL_dalpha;
-            const float Gs = ok ? G : 0.f;                  // exp2 of a skipped lane may be inf
-            const float gdx = Gs * dx, gdy = Gs * dy;
-            const float dG_ddx = -gdx * r0.z - gdy * r0.w, dG_ddy = -gdy * r1.x - gdx * r0.w;
-            // nine partial gradients of this pixel
-            float v0 = w * d0, v1 = w * d1, v2 = w * d2;
-            float v3 = dL_dG * dG_ddx * halfW, v4 = dL_dG * dG_ddy * halfH;
-            float v5 = -0.5f * gdx * dx * dL_dG, v6 = -0.5f * gdx * dy * dL_dG, v7 = -0.5f * gdy * dy * dL_dG;
-            float v8 = Gs * dL_dalpha;
-            v0 = row_allreduce(v0); v1 = row_allreduce(v1); v2 = row_allreduce(v2);
-            v3 = row_allreduce(v3); v4 = row_allreduce(v4); v5 = row_allreduce(v5);
-            v6 = row_allreduce(v6); v7 = row_allreduce(v7); v8 = row_allreduce(v8);
-            // lane (16 r + k) keeps row r's sum of value k, then rows are summed lane-wise
-            float sel = v0;
-            sel = k16 == 1 ? v1 : sel; sel = k16 == 2 ? v2 : sel; sel = k16 == 3 ? v3 : sel;
-            sel = k16 == 4 ? v4 : sel; sel = k16 == 5 ? v5 : sel; sel = k16 == 6 ? v6 : sel;
-            sel = k16 == 7 ? v7 : sel; sel = k16 == 8 ? v8 : sel;
-            sel += __shfl_xor(sel, 16);
-            sel += __shfl_xor(sel, 32);
-            if (lane < 9) {
-                const uint32_t g = my_id[j];
-                atomicAdd(a.acc + GSR_ACC_FLOATS * (size_t)g + lane, sel);
+        while (todo) {
+            const int j = 63 - __builtin_clzll(todo);
+            todo &= ~(1ull << j);
+            const float4 r0 = my[j * 3 + 0], r1 = my[j * 3 + 1], r2 = my[j * 3 + 2];
+            const uint32_t bits = __builtin_amdgcn_readfirstlane(__float_as_uint(r2.z));
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
+            bool any_live = false;
+#pragma unroll
+            for (int q = 0; q < NPX; q++) {
+                if (!(bits & (1u << q))) continue;    // scalar branch: block q cannot be reached
+                const float dx = r0.x - fx[q], dy = r0.y - fy[q];
+                const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
+                const float G = __builtin_amdgcn_exp2f(power * LOG2E);
+                const float alpha = fminf(GSR_ALPHA_MAX, r1.y * G);
+                const bool ok = (base + j < last[q]) && !(power > 0.f) && !(alpha < GSR_ALPHA_MIN);
+                if (!__any(ok)) continue;             // wave-uniform
+                any_live = true;
+                const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
+                const float Tk = ok ? Tr[q] * inv : Tr[q];          // transmittance in front of this splat
+                const float n0 = la[q] * lc0[q] + (1.f - la[q]) * acc0[q];   // colour accumulated behind it
+                const float n1 = la[q] * lc1[q] + (1.f - la[q]) * acc1[q];
+                const float n2 = la[q] * lc2[q] + (1.f - la[q]) * acc2[q];
+                float dL_dalpha = (r1.z - n0) * d0[q] + (r1.w - n1) * d1[q] + (r2.x - n2) * d2[q];
+                dL_dalpha = dL_dalpha * Tk - tb[q] * inv;
+                dL_dalpha = ok ? dL_dalpha : 0.f;
+                const float w = ok ? alpha * Tk : 0.f;
+                if (ok) { acc0[q] = n0; acc1[q] = n1; acc2[q] = n2; lc0[q] = r1.z; lc1[q] = r1.w; lc2[q] = r2.x; la[q] = alpha; }
+                Tr[q] = Tk;
+                const float dL_dG = r1.y * dL_dalpha;
+                const float Gs = ok ? G : 0.f;        // exp2 of a skipped lane may be inf
+                const float gdx = Gs * dx, gdy = Gs * dy;
+                v0 += w * d0[q]; v1 += w * d1[q]; v2 += w * d2[q];
+                v3 += dL_dG * (-gdx * r0.z - gdy * r0.w) * halfW;
+                v4 += dL_dG * (-gdy * r1.x - gdx * r0.w) * halfH;
+                const float hg = -0.5f * dL_dG;
+                v5 += hg * gdx * dx; v6 += hg * gdx * dy; v7 += hg * gdy * dy;
+                v8 += Gs * dL_dalpha;
+            }
+            if (!any_live) continue;                  // wave-uniform
+            float x0 = fold16(fold32(v0, v1), fold32(v2, v3));
+            float x1 = fold16(fold32(v4, v5), fold32(v6, v7));
+            float x2 = fold16(fold32(v8, 0.f), 0.f);
+            x0 = row_allreduce(x0); x1 = row_allreduce(x1); x2 = row_allreduce(x2);
+            const float sel = k16 == 0 ? x0 : (k16 == 1 ? x1 : x2);
+            if (slot >= 0) {
+                const uint32_t g = __float_as_uint(r2.w);
+                atomicAdd(a.acc + GSR_ACC_FLOATS * (size_t)g + slot, sel);
             }
         }
     }
 }
 
-hipError_t launch_composite_bwd(const CompositeBwdArgs &a, hipStream_t s) {
+template <int NPX>
+static hipError_t launch_bwd(const CompositeBwdArgs &a, int exact_cull, hipStream_t s) {
     const int T = a.gridx * a.gridy;
-    if (T <= 0) return hipSuccess;
-    const int padded = (T + 7) / 8 * 8;
-    hipLaunchKernelGGL(composite_bwd_kernel, dim3(padded), dim3(256), 0, s, a, padded);
+    const int units = T * (4 / NPX);
+    const int blocks = (units + 3) / 4;
+    const int padded = (blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL(composite_bwd_kernel<NPX>, dim3(padded), dim3(256), 0, s, a, padded, exact_cull);
     return hipGetLastError();
+}
+
+hipError_t launch_composite_bwd(const CompositeBwdArgs &a, int npx, int exact_cull, hipStream_t s) {
+    if (a.gridx * a.gridy <= 0) return hipSuccess;
+    switch (npx) {
+        case 1: return launch_bwd<1>(a, exact_cull, s);
+        case 2: return launch_bwd<2>(a, exact_cull, s);
+        default: return launch_bwd<4>(a, exact_cull, s);
+    }
 }
 
 }  // namespace gsr

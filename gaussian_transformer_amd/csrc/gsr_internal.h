@@ -94,7 +94,7 @@ struct CompositeBwdArgs {
     const float *dL_dpix;
     float *acc;   // [P][16], zeroed
 };
-hipError_t launch_composite_bwd(const CompositeBwdArgs &a, hipStream_t s);
+hipError_t launch_composite_bwd(const CompositeBwdArgs &a, int npx, int exact_cull, hipStream_t s);
 
 struct PergaussBwdArgs {
     int P, D, M, W, H;

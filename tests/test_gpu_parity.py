@@ -155,6 +155,28 @@ def test_forward_backward_parity(case):
     assert np.all(hg["means2D"][:, 2] == 0)
 
 
+@pytest.mark.parametrize("npx", [1, 2, 4])
+def test_backward_variants_blocks_per_wave(npx):
+    """The reverse compositing kernel is instantiated for 1, 2 and 4 8x8 blocks per wave."""
+    from gaussian_transformer_amd import _lib
+    _lib.set_option("bwd_blocks_per_wave", npx)
+    try:
+        for case in (1, 4):
+            c = CASES[case]
+            sc = synth.make_scene(**c["scene"])
+            S = oracle_scene(sc, **c["over"])
+            dL = np.random.default_rng(7).normal(size=(3, S.H, S.W)).astype(np.float32)
+            r = ref.get("f32")
+            f = r.forward(S); g = r.backward(f, dL)
+            h = hip_forward_backward(S, dL)
+            for a, b in [("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("shs", "dL_dsh"), ("scales", "dL_dscales"),
+                         ("rotations", "dL_drots")]:
+                assert grad_err(h["grads"][a], g[b]) < GRAD_RTOL, (npx, case, a)
+            assert grad_err(h["grads"]["opacities"].reshape(-1), g["dL_dopacity"]) < GRAD_RTOL
+    finally:
+        _lib.set_option("bwd_blocks_per_wave", 2)
+
+
 def test_precomputed_colour_and_covariance_parity():
     sc = synth.make_scene(P=1200, width=96, height=80, sh_degree=0, s0=0.05, seed=21, bg=(0.2, 0.3, 0.4))
     rng = np.random.default_rng(2)
