@@ -89,8 +89,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
     const float halfW = 0.5f * (float)a.W, halfH = 0.5f * (float)a.H;
     const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 
-    // per-pixel state, one pixel per 8x8 block q
-    float fx[NPX], fy[NPX], Tr[NPX], acc0[NPX], acc1[NPX], acc2[NPX], la[NPX], lc0[NPX], lc1[NPX], lc2[NPX];
+    // per-pixel state, one pixel per 8x8 block q:  Tr = transmittance behind the splats visited so far,
+    // acc = colour composited behind them (normalised by Tr), d = dL/dpixel, tb = T_final * <bg, d>
+    float fx[NPX], fy[NPX], Tr[NPX], acc0[NPX], acc1[NPX], acc2[NPX];
     float d0[NPX], d1[NPX], d2[NPX], tb[NPX];
     int last[NPX];
     float bxa[NPX], bya[NPX], bxb[NPX], byb[NPX];     // block rectangles (wave-uniform)
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
         d1[q] = inside ? a.dL_dpix[HW + pix] : 0.f;
         d2[q] = inside ? a.dL_dpix[2 * HW + pix] : 0.f;
         tb[q] = Tf * (bg0 * d0[q] + bg1 * d1[q] + bg2 * d2[q]);
-        Tr[q] = Tf; acc0[q] = acc1[q] = acc2[q] = 0.f; la[q] = 0.f; lc0[q] = lc1[q] = lc2[q] = 0.f;
+        Tr[q] = Tf; acc0[q] = acc1[q] = acc2[q] = 0.f;
         max_last = max(max_last, last[q]);
     }
 #pragma unroll
@@ -153,46 +154,45 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
             todo &= ~(1ull << j);
             const float4 r0 = my[j * 3 + 0], r1 = my[j * 3 + 1], r2 = my[j * 3 + 2];
             const uint32_t bits = __builtin_amdgcn_readfirstlane(__float_as_uint(r2.z));
+            // Per-lane partial sums over this lane's pixels.  The constant factors of S10 are applied
+            // once per Gaussian in pergauss_bwd.hip:  v3,v4 = sum s*u, s*v  (x -W/2, -H/2 there),
+            // v5..v7 = sum s*dx*dx, s*dx*dy, s*dy*dy (x -1/2 there), with s = o * G * dL/dalpha.
             float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
-            bool any_live = false;
+            const int pos = base + j;
 #pragma unroll
             for (int q = 0; q < NPX; q++) {
                 if (!(bits & (1u << q))) continue;    // scalar branch: block q cannot be reached
                 const float dx = r0.x - fx[q], dy = r0.y - fy[q];
-                const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
-                const float G = __builtin_amdgcn_exp2f(power * LOG2E);
+                const float u = r0.z * dx + r0.w * dy, v = r1.x * dy + r0.w * dx;    // conic * d
+                const float qf = dx * u + dy * v;                                   // = -2 power
+                const float G = __builtin_amdgcn_exp2f(qf * (-0.5f * LOG2E));
                 const float alpha = fminf(GSR_ALPHA_MAX, r1.y * G);
-                const bool ok = (base + j < last[q]) && !(power > 0.f) && !(alpha < GSR_ALPHA_MIN);
-                if (!__any(ok)) continue;             // wave-uniform
-                any_live = true;
-                const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
-                const float Tk = ok ? Tr[q] * inv : Tr[q];          // transmittance in front of this splat
-                const float n0 = la[q] * lc0[q] + (1.f - la[q]) * acc0[q];   // colour accumulated behind it
-                const float n1 = la[q] * lc1[q] + (1.f - la[q]) * acc1[q];
-                const float n2 = la[q] * lc2[q] + (1.f - la[q]) * acc2[q];
-                float dL_dalpha = (r1.z - n0) * d0[q] + (r1.w - n1) * d1[q] + (r2.x - n2) * d2[q];
-                dL_dalpha = dL_dalpha * Tk - tb[q] * inv;
+                const bool ok = (pos < last[q]) && !(qf < 0.f) && !(alpha < GSR_ALPHA_MIN);
+                const float a_ok = ok ? alpha : 0.f;
+                const float inv = __builtin_amdgcn_rcpf(1.f - a_ok);
+                const float Tk = Tr[q] * inv;                        // transmittance in front of this splat
+                const float t0 = r1.z - acc0[q], t1 = r1.w - acc1[q], t2 = r2.x - acc2[q];
+                float dL_dalpha = (t0 * d0[q] + t1 * d1[q] + t2 * d2[q]) * Tk - tb[q] * inv;
                 dL_dalpha = ok ? dL_dalpha : 0.f;
-                const float w = ok ? alpha * Tk : 0.f;
-                if (ok) { acc0[q] = n0; acc1[q] = n1; acc2[q] = n2; lc0[q] = r1.z; lc1[q] = r1.w; lc2[q] = r2.x; la[q] = alpha; }
+                acc0[q] += a_ok * t0; acc1[q] += a_ok * t1; acc2[q] += a_ok * t2;   // colour behind the next (nearer) splat
                 Tr[q] = Tk;
-                const float dL_dG = r1.y * dL_dalpha;
-                const float Gs = ok ? G : 0.f;        // exp2 of a skipped lane may be inf
-                const float gdx = Gs * dx, gdy = Gs * dy;
+                const float w = a_ok * Tk;
                 v0 += w * d0[q]; v1 += w * d1[q]; v2 += w * d2[q];
-                v3 += dL_dG * (-gdx * r0.z - gdy * r0.w) * halfW;
-                v4 += dL_dG * (-gdy * r1.x - gdx * r0.w) * halfH;
-                const float hg = -0.5f * dL_dG;
-                v5 += hg * gdx * dx; v6 += hg * gdx * dy; v7 += hg * gdy * dy;
-                v8 += Gs * dL_dalpha;
+                const float g8 = (ok ? G : 0.f) * dL_dalpha;         // exp2 of a skipped lane may be inf
+                const float sg = r1.y * g8;
+                v8 += g8;
+                v3 += sg * u; v4 += sg * v;
+                const float sx = sg * dx, sy = sg * dy;
+                v5 += sx * dx; v6 += sx * dy; v7 += sy * dy;
             }
-            if (!any_live) continue;                  // wave-uniform
             float x0 = fold16(fold32(v0, v1), fold32(v2, v3));
             float x1 = fold16(fold32(v4, v5), fold32(v6, v7));
             float x2 = fold16(fold32(v8, 0.f), 0.f);
             x0 = row_allreduce(x0); x1 = row_allreduce(x1); x2 = row_allreduce(x2);
             const float sel = k16 == 0 ? x0 : (k16 == 1 ? x1 : x2);
-            if (slot >= 0) {
+            // opacity weight sum == 0 for every lane <=> no pixel blended this splat: skip the atomic
+            const bool touched = __any(sel != 0.f);
+            if (touched && slot >= 0) {
                 const uint32_t g = __float_as_uint(r2.w);
                 atomicAdd(a.acc + GSR_ACC_FLOATS * (size_t)g + slot, sel);
             }

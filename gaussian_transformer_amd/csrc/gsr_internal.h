@@ -17,7 +17,7 @@ static inline int ceil_log2_u32(uint32_t x) { int b = 0; while ((1u << b) < x &&
 #define GSR_REC_FLOATS 12
 // Gradient accumulator of the reverse compositing pass: one 64-byte row per Gaussian so that the
 // nine atomics of one (tile, Gaussian) pair fall into a single memory-side atomic request.
-//   [0..2] dL/drgb  [3..4] dL/dmean2D (NDC)  [5..7] dL/dconic (xx, xy-half, yy)  [8] dL/dopacity
+//   [0..2] dL/drgb  [3..4] sum s*(conic d) (= dL/dmean2D / -(W/2,H/2))  [5..7] sum s*d d^T (= dL/dconic / -0.5)  [8] dL/dopacity
 #define GSR_ACC_FLOATS 16
 
 struct GeomView {          // per-Gaussian state, P entries each

@@ -27,8 +27,10 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
         const float4 A0 = acc4[0], A1 = acc4[1];
         const float A8 = a.acc[GSR_ACC_FLOATS * si + 8];
         dcol[0] = A0.x; dcol[1] = A0.y; dcol[2] = A0.z;
-        dm2[0] = A0.w; dm2[1] = A1.x;
-        const float gA = A1.y, gB = A1.z, gC = A1.w;
+        // constant factors of S10 deferred from the compositing kernel (composite_bwd.hip):
+        // mean2D gradient w.r.t. NDC = -(W/2, H/2) * sum s*(conic d);  conic gradient = -1/2 * sum s*d d^T
+        dm2[0] = -0.5f * (float)a.W * A0.w; dm2[1] = -0.5f * (float)a.H * A1.x;
+        const float gA = -0.5f * A1.y, gB = -0.5f * A1.z, gC = -0.5f * A1.w;
         dop = A8;
 
         const float p[3] = {a.means3D[3 * si], a.means3D[3 * si + 1], a.means3D[3 * si + 2]};
