@@ -52,26 +52,6 @@ __device__ __forceinline__ float fold16(float a, float b) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// exact minimum of q(d) = A dx^2 + 2 B dx dy + C dy^2 over the pixel rectangle [xa,xb] x [ya,yb]
-// (d = splat centre - pixel); compared with the splat's culling threshold tau
-__device__ __forceinline__ bool block_reachable(float px, float py, float A, float B, float C, float invA, float invC,
-                                                float tau, float xa, float xb, float ya, float yb) {
-    const float dxa = px - xa, dxb = px - xb, dya = py - ya, dyb = py - yb;   // dxb <= dx <= dxa, dyb <= dy <= dya
-    if (dxb <= 0.f && dxa >= 0.f && dyb <= 0.f && dya >= 0.f) return tau > 0.f;   // centre inside the block
-    float q;
-    {
-        float dy = fminf(fmaxf(-B * dxa * invC, dyb), dya);
-        q = (A * dxa + 2.f * B * dy) * dxa + C * dy * dy;
-        dy = fminf(fmaxf(-B * dxb * invC, dyb), dya);
-        q = fminf(q, (A * dxb + 2.f * B * dy) * dxb + C * dy * dy);
-        float dx = fminf(fmaxf(-B * dya * invA, dxb), dxa);
-        q = fminf(q, (A * dx + 2.f * B * dya) * dx + C * dya * dya);
-        dx = fminf(fmaxf(-B * dyb * invA, dxb), dxa);
-        q = fminf(q, (A * dx + 2.f * B * dyb) * dx + C * dyb * dyb);
-    }
-    return q <= tau;
-}
-
 template <int NPX>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, int nblocks_padded, int exact_cull) {
     constexpr int UNITS_PER_TILE = 4 / NPX;          // waves per tile

@@ -1,13 +1,16 @@
 // composite_fwd.hip -- front-to-back alpha compositing (S9).
 //
-// CDNA4 shape: a 256-thread workgroup owns one 16x16 tile, but its four wave64s are fully
-// independent: wave w composites the 8x8 pixel quadrant w of the tile, stages the tile's
-// depth-sorted splat list 64 records at a time into a wave-private 3 KiB LDS slice (one record
-// gathered per lane, read back as wave-uniform broadcast ds_read_b128), and stops as soon as its
-// own 64 pixels are saturated (64-bit ballot).  There is no workgroup barrier anywhere, so a
-// finished quadrant never waits for the slowest pixel of the tile.
-// Conic terms are pre-scaled by -0.5*log2(e) / -log2(e) at staging time so the per-pixel
-// exponent feeds v_exp_f32 directly.
+// CDNA4 shape: a wave64 owns NPX 8x8 pixel blocks of one 16x16 tile (4 = whole tile, 2 = upper or
+// lower half, 1 = one quadrant); lane l holds pixel l of each block.  Waves are fully independent
+// (no workgroup barrier): each stages the tile's depth-sorted splat list 64 records at a time into a
+// wave-private 3 KiB LDS slice (one record gathered per lane, read back as wave-uniform broadcast
+// ds_read_b128) and stops as soon as all of ITS pixels are saturated (64-bit ballot), so a finished
+// block never waits for the slowest pixel of the tile.  While staging, each lane decides per 8x8
+// block whether its splat can reach alpha >= 1/255 anywhere in the block (exact minimum of the
+// quadratic form over the block rectangle, gsr_device.h); the wave then walks only the set bits of
+// the ballot -- dead splats cost two scalar instructions -- and skips dead blocks of a live splat
+// with a scalar branch.  The conic is pre-scaled by -0.5*log2(e) / -log2(e) at staging time so the
+// per-pixel exponent feeds v_exp_f32 directly.
 // blockIdx is remapped so that each XCD (blocks b, b+8, ... share one) walks a contiguous band
 // of tiles: neighbouring tiles share splats, which keeps the record gathers in that XCD's L2.
 #include "gsr_device.h"
@@ -17,80 +20,134 @@ namespace gsr {
 
 #define LOG2E 1.4426950408889634f
 
-__device__ __forceinline__ int xcd_band_tile(int b, int nblocks_padded) {
+__device__ __forceinline__ int xcd_band_unit_f(int b, int nblocks_padded) {
     const int chunk = nblocks_padded >> 3;
     return (b & 7) * chunk + (b >> 3);
 }
 
-__global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int nblocks_padded) {
+template <int NPX>
+__global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int nblocks_padded, int exact_cull) {
+    constexpr int UNITS_PER_TILE = 4 / NPX;
     __shared__ float4 stage[4][64 * 3];
     const int T = a.gridx * a.gridy;
-    const int tile = xcd_band_tile(blockIdx.x, nblocks_padded);
-    if (tile >= T) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int unit = xcd_band_unit_f(blockIdx.x, nblocks_padded) * 4 + wave;
+    const int tile = unit / UNITS_PER_TILE, sub = unit % UNITS_PER_TILE;
+    if (tile >= T) return;                            // wave-uniform
     const int tx = tile % a.gridx, ty = tile / a.gridx;
-    const int x = tx * GSR_TILE + (wave & 1) * 8 + (lane & 7);
-    const int y = ty * GSR_TILE + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = x < a.W && y < a.H;
-    const float fx = (float)x, fy = (float)y;
     const uint2 range = a.ranges[tile];
     const int n = (int)(range.y - range.x);
     float4 *my = stage[wave];
     const float4 *rec4 = reinterpret_cast<const float4 *>(a.rec);
 
-    float Tr = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    uint32_t last = 0;
-    bool done = !inside;
+    float fx[NPX], fy[NPX], Tr[NPX], C0[NPX], C1[NPX], C2[NPX];
+    uint32_t last[NPX];
+    bool done[NPX], inside[NPX];
+    float bxa[NPX], bya[NPX], bxb[NPX], byb[NPX];
+    bool all_done = true;
+#pragma unroll
+    for (int q = 0; q < NPX; q++) {
+        const int blk = NPX == 4 ? q : (NPX == 2 ? sub * 2 + q : sub);
+        const int x0 = tx * GSR_TILE + (blk & 1) * 8, y0 = ty * GSR_TILE + (blk >> 1) * 8;
+        const int x = x0 + (lane & 7), y = y0 + (lane >> 3);
+        inside[q] = x < a.W && y < a.H;
+        fx[q] = (float)x; fy[q] = (float)y;
+        bxa[q] = (float)x0; bya[q] = (float)y0;
+        bxb[q] = (float)min(x0 + 7, a.W - 1); byb[q] = (float)min(y0 + 7, a.H - 1);
+        Tr[q] = 1.f; C0[q] = C1[q] = C2[q] = 0.f; last[q] = 0u;
+        done[q] = !inside[q];
+        all_done = all_done && done[q];
+    }
 
     for (int base = 0; base < n; base += 64) {
-        if (__all(done)) break;
+        if (__all(all_done)) break;                   // wave-uniform
         const int cnt = min(64, n - base);
         __builtin_amdgcn_wave_barrier();
+        bool live = false;
         if (lane < cnt) {
             const uint32_t g = a.point_list[range.x + base + lane];
             float4 r0 = rec4[3 * (size_t)g], r1 = rec4[3 * (size_t)g + 1];
-            const float b = a.rec[GSR_REC_FLOATS * (size_t)g + 8];
-            // (px, py, -0.5*log2e*A, -log2e*B) (-0.5*log2e*C, opacity, r, g) (b)
+            const float4 r2 = rec4[3 * (size_t)g + 2];
+            uint32_t bits = (1u << NPX) - 1u;
+            if (exact_cull && r2.z > 0.f) {           // tau == 0: forward ran with culling off -> no information
+                const float invA = 1.f / r0.z, invC = 1.f / r1.x;
+                bits = 0u;
+#pragma unroll
+                for (int q = 0; q < NPX; q++)
+                    bits |= block_reachable(r0.x, r0.y, r0.z, r0.w, r1.x, invA, invC, r2.z, bxa[q], bxb[q], bya[q], byb[q]) ? (1u << q) : 0u;
+            }
+            live = bits != 0u;
+            // (px, py, -0.5*log2e*A, -log2e*B) (-0.5*log2e*C, opacity, r, g) (b, -, block bits, -)
             r0.z *= -0.5f * LOG2E; r0.w *= -LOG2E; r1.x *= -0.5f * LOG2E;
-            my[lane * 3 + 0] = r0; my[lane * 3 + 1] = r1; my[lane * 3 + 2] = make_float4(b, 0.f, 0.f, 0.f);
+            my[lane * 3 + 0] = r0; my[lane * 3 + 1] = r1;
+            my[lane * 3 + 2] = make_float4(r2.x, 0.f, __uint_as_float(bits), 0.f);
         }
+        uint64_t todo = __ballot(live);
         __builtin_amdgcn_wave_barrier();
-        for (int j = 0; j < cnt; j++) {
-            const float4 r0 = my[j * 3 + 0], r1 = my[j * 3 + 1];
-            const float cb = reinterpret_cast<const float *>(my)[j * 12 + 8];
-            const float dx = r0.x - fx, dy = r0.y - fy;
-            const float power = (r0.z * dx + r0.w * dy) * dx + (r1.x * dy) * dy;   // log2 units
-            const float alpha = fminf(GSR_ALPHA_MAX, r1.y * __builtin_amdgcn_exp2f(power));
-            const bool ok = !done && !(power > 0.f) && !(alpha < GSR_ALPHA_MIN);
-            const float Tn = Tr * (1.f - alpha);
-            const bool stop = ok && (Tn < GSR_T_MIN);
-            done = done || stop;
-            const bool blend = ok && !stop;
-            const float w = blend ? alpha * Tr : 0.f;
-            C0 += r1.z * w; C1 += r1.w * w; C2 += cb * w;
-            Tr = blend ? Tn : Tr;
-            last = blend ? (uint32_t)(base + j + 1) : last;
-            if (__any(stop)) {                      // wave-uniform
-                if (__all(done)) break;
+        while (todo) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float4 r0 = my[j * 3 + 0], r1 = my[j * 3 + 1], r2 = my[j * 3 + 2];
+            const uint32_t bits = __builtin_amdgcn_readfirstlane(__float_as_uint(r2.z));
+            const uint32_t pos = (uint32_t)(base + j + 1);
+            bool any_stop = false;
+#pragma unroll
+            for (int q = 0; q < NPX; q++) {
+                if (!(bits & (1u << q))) continue;    // scalar branch
+                const float dx = r0.x - fx[q], dy = r0.y - fy[q];
+                const float power = (r0.z * dx + r0.w * dy) * dx + (r1.x * dy) * dy;   // log2 units
+                const float alpha = fminf(GSR_ALPHA_MAX, r1.y * __builtin_amdgcn_exp2f(power));
+                const bool ok = !done[q] && !(power > 0.f) && !(alpha < GSR_ALPHA_MIN);
+                const float Tn = Tr[q] * (1.f - alpha);
+                const bool stop = ok && (Tn < GSR_T_MIN);
+                done[q] = done[q] || stop;
+                any_stop = any_stop || stop;
+                const bool blend = ok && !stop;
+                const float w = blend ? alpha * Tr[q] : 0.f;
+                C0[q] += r1.z * w; C1[q] += r1.w * w; C2[q] += r2.x * w;
+                Tr[q] = blend ? Tn : Tr[q];
+                last[q] = blend ? pos : last[q];
+            }
+            if (__any(any_stop)) {                    // wave-uniform
+                all_done = true;
+#pragma unroll
+                for (int q = 0; q < NPX; q++) all_done = all_done && done[q];
+                if (__all(all_done)) { todo = 0; }
             }
         }
     }
-    if (inside) {
-        const size_t pix = (size_t)y * a.W + x, HW = (size_t)a.W * a.H;
-        a.final_T[pix] = Tr;
-        a.n_contrib[pix] = last;
-        a.out_color[pix] = C0 + Tr * a.bg[0];
-        a.out_color[HW + pix] = C1 + Tr * a.bg[1];
-        a.out_color[2 * HW + pix] = C2 + Tr * a.bg[2];
+    const size_t HW = (size_t)a.W * a.H;
+    const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+#pragma unroll
+    for (int q = 0; q < NPX; q++) {
+        if (inside[q]) {
+            const size_t pix = (size_t)fy[q] * a.W + (size_t)fx[q];
+            a.final_T[pix] = Tr[q];
+            a.n_contrib[pix] = last[q];
+            a.out_color[pix] = C0[q] + Tr[q] * bg0;
+            a.out_color[HW + pix] = C1[q] + Tr[q] * bg1;
+            a.out_color[2 * HW + pix] = C2[q] + Tr[q] * bg2;
+        }
     }
 }
 
-hipError_t launch_composite_fwd(const CompositeArgs &a, hipStream_t s) {
+template <int NPX>
+static hipError_t launch_fwd(const CompositeArgs &a, int exact_cull, hipStream_t s) {
     const int T = a.gridx * a.gridy;
-    if (T <= 0) return hipSuccess;
-    const int padded = (T + 7) / 8 * 8;
-    hipLaunchKernelGGL(composite_fwd_kernel, dim3(padded), dim3(256), 0, s, a, padded);
+    const int units = T * (4 / NPX);
+    const int blocks = (units + 3) / 4;
+    const int padded = (blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL(composite_fwd_kernel<NPX>, dim3(padded), dim3(256), 0, s, a, padded, exact_cull);
     return hipGetLastError();
+}
+
+hipError_t launch_composite_fwd(const CompositeArgs &a, int npx, int exact_cull, hipStream_t s) {
+    if (a.gridx * a.gridy <= 0) return hipSuccess;
+    switch (npx) {
+        case 1: return launch_fwd<1>(a, exact_cull, s);
+        case 2: return launch_fwd<2>(a, exact_cull, s);
+        default: return launch_fwd<4>(a, exact_cull, s);
+    }
 }
 
 }  // namespace gsr

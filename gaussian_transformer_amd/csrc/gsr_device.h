@@ -252,6 +252,26 @@ __device__ __forceinline__ void tile_row_span(const CullParams &c, float px, flo
     if (t1 > t0) { c0 = t0; c1 = t1; }
 }
 
+// exact minimum of q(d) = A dx^2 + 2 B dx dy + C dy^2 over the pixel rectangle [xa,xb] x [ya,yb]
+// (d = splat centre - pixel); compared with the splat's culling threshold tau
+__device__ __forceinline__ bool block_reachable(float px, float py, float A, float B, float C, float invA, float invC,
+                                                float tau, float xa, float xb, float ya, float yb) {
+    const float dxa = px - xa, dxb = px - xb, dya = py - ya, dyb = py - yb;   // dxb <= dx <= dxa, dyb <= dy <= dya
+    if (dxb <= 0.f && dxa >= 0.f && dyb <= 0.f && dya >= 0.f) return tau > 0.f;   // centre inside the block
+    float q;
+    {
+        float dy = fminf(fmaxf(-B * dxa * invC, dyb), dya);
+        q = (A * dxa + 2.f * B * dy) * dxa + C * dy * dy;
+        dy = fminf(fmaxf(-B * dxb * invC, dyb), dya);
+        q = fminf(q, (A * dxb + 2.f * B * dy) * dxb + C * dy * dy);
+        float dx = fminf(fmaxf(-B * dya * invA, dxb), dxa);
+        q = fminf(q, (A * dx + 2.f * B * dya) * dx + C * dya * dya);
+        dx = fminf(fmaxf(-B * dyb * invA, dxb), dxa);
+        q = fminf(q, (A * dx + 2.f * B * dyb) * dx + C * dyb * dyb);
+    }
+    return q <= tau;
+}
+
 // Load the first 3*K floats of one Gaussian's SH row [M,3] into c[].  16-byte vector loads when
 // the row stride keeps every row 16-byte aligned (M = 4, 8, 12, 16 ...), scalar loads otherwise.
 template <int K>

@@ -81,7 +81,7 @@ struct CompositeArgs {
     uint32_t *n_contrib;
     float *out_color;
 };
-hipError_t launch_composite_fwd(const CompositeArgs &a, hipStream_t s);
+hipError_t launch_composite_fwd(const CompositeArgs &a, int npx, int exact_cull, hipStream_t s);
 
 struct CompositeBwdArgs {
     int W, H, gridx, gridy;

@@ -160,6 +160,7 @@ def test_backward_variants_blocks_per_wave(npx):
     """The reverse compositing kernel is instantiated for 1, 2 and 4 8x8 blocks per wave."""
     from gaussian_transformer_amd import _lib
     _lib.set_option("bwd_blocks_per_wave", npx)
+    _lib.set_option("fwd_blocks_per_wave", npx)
     try:
         for case in (1, 4):
             c = CASES[case]
@@ -169,12 +170,14 @@ def test_backward_variants_blocks_per_wave(npx):
             r = ref.get("f32")
             f = r.forward(S); g = r.backward(f, dL)
             h = hip_forward_backward(S, dL)
+            assert_image_close(h["color"], f["color"])
             for a, b in [("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("shs", "dL_dsh"), ("scales", "dL_dscales"),
                          ("rotations", "dL_drots")]:
                 assert grad_err(h["grads"][a], g[b]) < GRAD_RTOL, (npx, case, a)
             assert grad_err(h["grads"]["opacities"].reshape(-1), g["dL_dopacity"]) < GRAD_RTOL
     finally:
         _lib.set_option("bwd_blocks_per_wave", 2)
+        _lib.set_option("fwd_blocks_per_wave", 2)
 
 
 def test_precomputed_colour_and_covariance_parity():
