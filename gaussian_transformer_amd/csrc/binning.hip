@@ -43,11 +43,99 @@ hipError_t launch_sort(const BinningView &b, int64_t N, int bits, hipStream_t s)
                                      (unsigned)bits, s, false);
 }
 
-__global__ __launch_bounds__(256) void emit_keys_kernel(int P, int W, int H, int gridx, int exact_cull,
+// ---- two-level sort: rocPRIM orders the pairs by TILE only (stable, 2 onesweep passes over
+// ceil(log2 T) bits instead of 5 over 32+log2 T), then one workgroup per tile orders its
+// contiguous slice by (depth bits, Gaussian id) in LDS.  Within a tile the stable tile sort keeps
+// emission order = ascending Gaussian id, so (depth, id) reproduces exactly the order of a global
+// stable sort on tile<<32|depth.
+hipError_t sort2_temp_bytes(int64_t N, int tile_bits, size_t *bytes) {
+    size_t tb = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tb, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                             (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                             (size_t)(N > 0 ? N : 1), 0u, (unsigned)tile_bits, (hipStream_t)0, false);
+    *bytes = tb;
+    return e;
+}
+
+hipError_t launch_sort2_by_tile(const BinningView &b, int64_t N, int tile_bits, hipStream_t s) {
+    size_t tb = b.sort_temp_bytes;
+    return rocprim::radix_sort_pairs(b.sort_temp, tb, (const uint32_t *)b.tkeys_unsorted, b.tkeys_sorted,
+                                     (const uint64_t *)b.dvals_unsorted, b.dvals_sorted, (size_t)N, 0u,
+                                     (unsigned)tile_bits, s, false);
+}
+
+// One workgroup per tile: bitonic sort of the tile's (depth<<32 | id) words in LDS, ids out.
+// CAP = LDS capacity in elements; the kernel instance handles tiles with LO < n <= CAP.  The last
+// instance (CAP = 16384) also takes larger tiles through a (slow) in-place global-memory path.
+template <int CAP, int LO, bool LAST>
+__global__ __launch_bounds__(256) void tile_depth_sort_kernel(const uint2 *__restrict__ ranges,
+                                                              uint64_t *__restrict__ dvals,
+                                                              uint32_t *__restrict__ point_list,
+                                                              uint32_t *__restrict__ scratch) {
+    extern __shared__ __align__(16) uint64_t lds_keys[];
+    const uint2 r = ranges[blockIdx.x];
+    const uint32_t n = r.y - r.x;
+    if (n <= (uint32_t)LO || (!LAST && n > (uint32_t)CAP)) return;     // workgroup-uniform
+    const uint32_t tid = threadIdx.x;
+    const uint64_t *src = dvals + r.x;
+    if (n == 1) { if (tid == 0) point_list[r.x] = (uint32_t)src[0]; return; }
+    uint32_t m = 2;
+    while (m < n) m <<= 1;
+    if (LAST && n > (uint32_t)CAP) {
+        // rare (> 16384 pairs in one tile): rank sort, keys streamed through LDS in CAP-sized chunks.
+        // All keys of a tile are distinct (the id is part of the key), so rank = #smaller keys.
+        for (uint32_t i = tid; i < n; i += 256) scratch[r.x + i] = 0u;
+        for (uint32_t c0 = 0; c0 < n; c0 += CAP) {
+            const uint32_t cn = min((uint32_t)CAP, n - c0);
+            __syncthreads();
+            for (uint32_t i = tid; i < cn; i += 256) lds_keys[i] = src[c0 + i];
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += 256) {
+                const uint64_t mine = src[i];
+                uint32_t less = 0;
+                for (uint32_t t = 0; t < cn; t++) less += lds_keys[t] < mine ? 1u : 0u;
+                scratch[r.x + i] += less;
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += 256) point_list[r.x + scratch[r.x + i]] = (uint32_t)src[i];
+        return;
+    }
+    for (uint32_t i = tid; i < m; i += 256) lds_keys[i] = i < n ? src[i] : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= m; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t p = tid; p < (m >> 1); p += 256) {
+                const uint32_t i = ((p / j) * (j << 1)) + (p % j), l = i + j;     // j is a power of two
+                const bool asc = (i & k) == 0;
+                const uint64_t a = lds_keys[i], bb = lds_keys[l];
+                if ((a > bb) == asc) { lds_keys[i] = bb; lds_keys[l] = a; }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = tid; i < n; i += 256) point_list[r.x + i] = (uint32_t)lds_keys[i];
+}
+
+hipError_t launch_tile_depth_sort(const BinningView &b, const ImageView &im, int T, hipStream_t s) {
+    if (T <= 0) return hipSuccess;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)tile_depth_sort_kernel<16384, 4096, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((tile_depth_sort_kernel<1024, 0, false>), dim3(T), dim3(256), 1024 * 8, s, im.ranges, b.dvals_sorted, b.point_list, (uint32_t *)b.dvals_unsorted);
+    hipLaunchKernelGGL((tile_depth_sort_kernel<4096, 1024, false>), dim3(T), dim3(256), 4096 * 8, s, im.ranges, b.dvals_sorted, b.point_list, (uint32_t *)b.dvals_unsorted);
+    hipLaunchKernelGGL((tile_depth_sort_kernel<16384, 4096, true>), dim3(T), dim3(256), 16384 * 8, s, im.ranges, b.dvals_sorted, b.point_list, (uint32_t *)b.dvals_unsorted);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void emit_keys_kernel(int P, int W, int H, int gridx, int exact_cull, int two_level,
                                                         const uint32_t *__restrict__ tiles,
                                                         const uint32_t *__restrict__ offsets,
                                                         const uint2 *__restrict__ rect, const float *__restrict__ rec,
-                                                        uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+                                                        uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                        uint32_t *__restrict__ tkeys, uint64_t *__restrict__ dvals) {
     const int lane = threadIdx.x & 63;
     const int g0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
     if (g0 >= P) return;                                  // wave-uniform
@@ -107,18 +195,25 @@ __global__ __launch_bounds__(256) void emit_keys_kernel(int P, int W, int H, int
         if (pass && slot < out_total) {                   // slot < out_total always holds (same span function as the count)
             const uint32_t tile = (y0 + ty) * (uint32_t)gridx + (x0 + tx);
             const size_t o = (size_t)out_start + slot;
-            keys[o] = ((uint64_t)tile << 32) | db;
-            vals[o] = (uint32_t)(g0 + src);
+            if (two_level) {                              // wave-uniform
+                tkeys[o] = tile;
+                dvals[o] = ((uint64_t)db << 32) | (uint32_t)(g0 + src);
+            } else {
+                keys[o] = ((uint64_t)tile << 32) | db;
+                vals[o] = (uint32_t)(g0 + src);
+            }
         }
         running += (uint32_t)__popcll(ballot);
     }
 }
 
-hipError_t launch_emit_keys(const GeomView &g, const BinningView &b, int P, int W, int H, int exact_cull, hipStream_t s) {
+hipError_t launch_emit_keys(const GeomView &g, const BinningView &b, int P, int W, int H, int exact_cull, int two_level,
+                            hipStream_t s) {
     if (P <= 0) return hipSuccess;
     const int gridx = (W + GSR_TILE - 1) / GSR_TILE;
-    hipLaunchKernelGGL(emit_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, W, H, gridx, exact_cull, g.tiles,
-                       g.offsets, g.rect, g.rec, b.keys_unsorted, b.point_list_unsorted);
+    hipLaunchKernelGGL(emit_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, W, H, gridx, exact_cull, two_level,
+                       g.tiles, g.offsets, g.rect, g.rec, b.keys_unsorted, b.point_list_unsorted, b.tkeys_unsorted,
+                       b.dvals_unsorted);
     return hipGetLastError();
 }
 
@@ -136,10 +231,26 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t N, const uint6
     if (j == N - 1) ranges[t].y = (uint32_t)N;
 }
 
-hipError_t launch_ranges(const BinningView &b, const ImageView &im, int64_t N, int T, hipStream_t s) {
+__global__ __launch_bounds__(256) void tile_ranges32_kernel(int64_t N, const uint32_t *__restrict__ tkeys,
+                                                            uint2 *__restrict__ ranges) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const uint32_t t = tkeys[j];
+    if (j == 0) {
+        ranges[t].x = 0u;
+    } else {
+        const uint32_t tp = tkeys[j - 1];
+        if (tp != t) { ranges[tp].y = (uint32_t)j; ranges[t].x = (uint32_t)j; }
+    }
+    if (j == N - 1) ranges[t].y = (uint32_t)N;
+}
+
+hipError_t launch_ranges(const BinningView &b, const ImageView &im, int64_t N, int T, int two_level, hipStream_t s) {
     hipError_t e = hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)T, s);
     if (e != hipSuccess || N <= 0) return e;
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, b.keys_sorted, im.ranges);
+    const dim3 grid((unsigned)((N + 255) / 256));
+    if (two_level) hipLaunchKernelGGL(tile_ranges32_kernel, grid, dim3(256), 0, s, N, b.tkeys_sorted, im.ranges);
+    else hipLaunchKernelGGL(tile_ranges_kernel, grid, dim3(256), 0, s, N, b.keys_sorted, im.ranges);
     return hipGetLastError();
 }
 

@@ -18,7 +18,8 @@ static thread_local char g_err[512] = "";
 static std::atomic<int> g_profiling{0};
 static std::atomic<int> g_exact_cull{1};
 static std::atomic<int> g_bwd_npx{2};
-static std::atomic<int> g_fwd_npx{2};      // same for the forward compositing kernel      // 8x8 pixel blocks per wave in the reverse compositing kernel (1, 2 or 4)   // output-invariant exact splat-vs-tile culling (gsr_set_option)
+static std::atomic<int> g_fwd_npx{2};
+static std::atomic<int> g_two_level_sort{1};   // 1: rocPRIM by tile + per-tile LDS depth sort; 0: one global 64-bit-key sort      // same for the forward compositing kernel      // 8x8 pixel blocks per wave in the reverse compositing kernel (1, 2 or 4)   // output-invariant exact splat-vs-tile culling (gsr_set_option)
 static float g_stage_ms[GSR_NUM_STAGES] = {0};
 static const char *const k_stage_names[GSR_NUM_STAGES] = {
     "fwd.preprocess", "fwd.scan", "fwd.readback_N", "fwd.emit_keys", "fwd.sort", "fwd.ranges", "fwd.composite",
@@ -79,6 +80,8 @@ BinningView carve_binning(void *base, int64_t N, size_t sort_tb) {
     b.keys_sorted = (uint64_t *)take(n * sizeof(uint64_t));
     b.keys_unsorted = (uint64_t *)take(n * sizeof(uint64_t));
     b.point_list_unsorted = (uint32_t *)take(n * sizeof(uint32_t));
+    b.tkeys_unsorted = b.point_list; b.dvals_sorted = b.keys_sorted; b.dvals_unsorted = b.keys_unsorted;
+    b.tkeys_sorted = b.point_list_unsorted;
     b.sort_temp = take(sort_tb);
     b.sort_temp_bytes = sort_tb;
     b.total_bytes = off;
@@ -86,7 +89,17 @@ BinningView carve_binning(void *base, int64_t N, size_t sort_tb) {
 }
 
 static inline int grid_dim(int px) { return (px + GSR_TILE_HOST - 1) / GSR_TILE_HOST; }
-static inline int key_bits(int W, int H) { return 32 + ceil_log2_u32((uint32_t)(grid_dim(W) * grid_dim(H))); }
+static inline int tile_bits(int W, int H) { return ceil_log2_u32((uint32_t)(grid_dim(W) * grid_dim(H))); }
+static inline int key_bits(int W, int H) { return 32 + tile_bits(W, H); }
+// temp storage that serves either sort flavour
+static hipError_t any_sort_temp_bytes(int64_t N, int W, int H, size_t *bytes) {
+    size_t a = 0, b = 0;
+    hipError_t e = sort_temp_bytes(N, key_bits(W, H), &a);
+    if (e != hipSuccess) return e;
+    e = sort2_temp_bytes(N, tile_bits(W, H) > 0 ? tile_bits(W, H) : 1, &b);
+    *bytes = a > b ? a : b;
+    return e;
+}
 
 struct StageTimer {   // hipEvent pairs on the caller's stream; active only under gsr_set_profiling(1)
     hipStream_t s;
@@ -129,6 +142,7 @@ const char *gsr_last_error(void) { return g_err; }
 
 int32_t gsr_set_option(const char *name, int32_t value) {
     if (name && !strcmp(name, "exact_tile_cull")) { g_exact_cull.store(value ? 1 : 0); return GSR_OK; }
+    if (name && !strcmp(name, "two_level_sort")) { g_two_level_sort.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "fwd_blocks_per_wave")) {
         if (value != 1 && value != 2 && value != 4) return fail(GSR_ERR_INVALID_ARGUMENT, "fwd_blocks_per_wave must be 1, 2 or 4");
         g_fwd_npx.store(value); return GSR_OK;
@@ -143,6 +157,7 @@ int32_t gsr_get_option(const char *name, int32_t *value) {
     if (name && value && !strcmp(name, "exact_tile_cull")) { *value = g_exact_cull.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "bwd_blocks_per_wave")) { *value = g_bwd_npx.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "fwd_blocks_per_wave")) { *value = g_fwd_npx.load(); return GSR_OK; }
+    if (name && value && !strcmp(name, "two_level_sort")) { *value = g_two_level_sort.load(); return GSR_OK; }
     return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_get_option: unknown option '%s'", name ? name : "(null)");
 }
 
@@ -169,7 +184,7 @@ int32_t gsr_workspace_sizes(int32_t P, int32_t W, int32_t H, size_t *geom_bytes,
 int32_t gsr_binning_bytes(int64_t N, int32_t W, int32_t H, size_t *bytes) {
     if (N < 0 || W <= 0 || H <= 0 || !bytes) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_binning_bytes: bad argument");
     size_t stb = 0;
-    HIP_TRY(sort_temp_bytes(N, key_bits(W, H), &stb), "sort temp query");
+    HIP_TRY(any_sort_temp_bytes(N, W, H, &stb), "sort temp query");
     *bytes = carve_binning(nullptr, N, stb).total_bytes;
     return GSR_OK;
 }
@@ -233,22 +248,28 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
 
     size_t sort_tb = 0;
     const int bits = key_bits(W, H);
-    HIP_TRY(sort_temp_bytes(N, bits, &sort_tb), "sort temp query");
+    const int two_level = g_two_level_sort.load();
+    HIP_TRY(any_sort_temp_bytes(N, W, H, &sort_tb), "sort temp query");
     BinningView b = carve_binning(nullptr, N, sort_tb);
     void *bin_ptr = binning_alloc(binning_user, b.total_bytes);
     if (!bin_ptr) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL for %zu bytes (N=%lld)", b.total_bytes, (long long)N);
     b = carve_binning(bin_ptr, N, sort_tb);
     tm.mark(3);
     if (N > 0) {
-        HIP_TRY(launch_emit_keys(g, b, P, W, H, pa.exact_cull, s), "emit keys launch");
+        HIP_TRY(launch_emit_keys(g, b, P, W, H, pa.exact_cull, two_level, s), "emit keys launch");
         if (debug) HIP_TRY(hipStreamSynchronize(s), "emit keys");
         tm.mark(4);
-        HIP_TRY(launch_sort(b, N, bits, s), "radix sort");
+        if (two_level) HIP_TRY(launch_sort2_by_tile(b, N, tile_bits(W, H) > 0 ? tile_bits(W, H) : 1, s), "radix sort by tile");
+        else HIP_TRY(launch_sort(b, N, bits, s), "radix sort");
         if (debug) HIP_TRY(hipStreamSynchronize(s), "radix sort");
     }
     tm.mark(5);
-    HIP_TRY(launch_ranges(b, im, N, T, s), "tile ranges");
+    HIP_TRY(launch_ranges(b, im, N, T, two_level, s), "tile ranges");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "tile ranges");
+    if (two_level && N > 0) {
+        HIP_TRY(launch_tile_depth_sort(b, im, T, s), "per-tile depth sort");
+        if (debug) HIP_TRY(hipStreamSynchronize(s), "per-tile depth sort");
+    }
     tm.mark(6);
     CompositeArgs ca;
     ca.W = W; ca.H = H; ca.gridx = gridx; ca.gridy = gridy; ca.ranges = im.ranges; ca.point_list = b.point_list;
@@ -363,6 +384,7 @@ int32_t gsr_debug_read_binning(gsr_stream_t stream, int64_t N, int32_t W, int32_
     HIP_TRY(hipStreamSynchronize(s), "sync");
     if (N > 0 && binning_ws) {
         BinningView b = carve_binning(const_cast<void *>(binning_ws), N, 0);
+        // global-sort mode: tile<<32|depth ; two-level mode: depth<<32|id grouped by tile
         if (keys_sorted) HIP_TRY(hipMemcpy(keys_sorted, b.keys_sorted, (size_t)N * 8, hipMemcpyDeviceToHost), "copy keys");
         if (point_list) HIP_TRY(hipMemcpy(point_list, b.point_list, (size_t)N * 4, hipMemcpyDeviceToHost), "copy point list");
     }

@@ -42,10 +42,18 @@ struct ImageView {
 ImageView carve_image(void *base, int W, int H);
 
 struct BinningView {
+    // one 24-byte-per-pair arena, two interpretations (regions A 4N | B 8N | C 8N | D 4N):
+    //   global sort  : A point_list (sorted ids) | B keys_sorted u64 | C keys_unsorted u64 | D ids_unsorted
+    //   two-level    : A tile keys unsorted, then point_list (the tile keys are dead once rocPRIM has
+    //                  read them) | B (depth<<32|id) sorted by tile | C same, unsorted | D tile keys sorted
     uint32_t *point_list;        // [N] sorted Gaussian ids           (read by backward)
     uint64_t *keys_sorted;       // [N]
     uint64_t *keys_unsorted;     // [N]
     uint32_t *point_list_unsorted;  // [N]
+    uint32_t *tkeys_unsorted;    // = A
+    uint64_t *dvals_sorted;      // = B
+    uint64_t *dvals_unsorted;    // = C
+    uint32_t *tkeys_sorted;      // = D
     void *sort_temp;
     size_t sort_temp_bytes;
     size_t total_bytes;
@@ -67,9 +75,12 @@ hipError_t scan_temp_bytes(int P, size_t *bytes);
 hipError_t launch_scan(const GeomView &g, int P, hipStream_t s);
 
 hipError_t sort_temp_bytes(int64_t N, int bits, size_t *bytes);
-hipError_t launch_emit_keys(const GeomView &g, const BinningView &b, int P, int W, int H, int exact_cull, hipStream_t s);
+hipError_t launch_emit_keys(const GeomView &g, const BinningView &b, int P, int W, int H, int exact_cull, int two_level, hipStream_t s);
+hipError_t sort2_temp_bytes(int64_t N, int tile_bits, size_t *bytes);
+hipError_t launch_sort2_by_tile(const BinningView &b, int64_t N, int tile_bits, hipStream_t s);
+hipError_t launch_tile_depth_sort(const BinningView &b, const ImageView &im, int T, hipStream_t s);
 hipError_t launch_sort(const BinningView &b, int64_t N, int bits, hipStream_t s);
-hipError_t launch_ranges(const BinningView &b, const ImageView &im, int64_t N, int T, hipStream_t s);
+hipError_t launch_ranges(const BinningView &b, const ImageView &im, int64_t N, int T, int two_level, hipStream_t s);
 
 struct CompositeArgs {
     int W, H, gridx, gridy;

@@ -53,12 +53,24 @@ def upstream_tile_rule():
     _lib.set_option("exact_tile_cull", 1)
 
 
+@pytest.mark.parametrize("two_level", [0, 1])
 @pytest.mark.parametrize("kw", [
     dict(P=3000, width=160, height=112, sh_degree=3, s0=0.03, seed=0),
     dict(P=1500, width=100, height=57, sh_degree=1, s0=0.06, seed=1, zmin=0.05, zmax=5.0),   # culled splats, ragged tiles
     dict(P=500, width=33, height=47, sh_degree=0, s0=0.5, seed=2),                            # huge splats: every tile
+    dict(P=3000, width=40, height=24, sh_degree=0, s0=0.6, seed=4),      # ~3000 pairs per tile: 4096-element LDS class
+    dict(P=20000, width=32, height=32, sh_degree=0, s0=0.8, seed=5),     # ~20000 pairs per tile: beyond LDS, rank-sort path
 ])
-def test_stages_bit_exact_against_oracle(kw, upstream_tile_rule):
+def test_stages_bit_exact_against_oracle(kw, two_level, upstream_tile_rule):
+    from gaussian_transformer_amd import _lib
+    _lib.set_option("two_level_sort", two_level)
+    try:
+        _check_stages_bit_exact(kw, two_level)
+    finally:
+        _lib.set_option("two_level_sort", 1)
+
+
+def _check_stages_bit_exact(kw, two_level):
     sc = synth.make_scene(**kw)
     S = oracle_scene(sc, scale_modifier=1.0)
     f = ref.get("f32").forward(S)
@@ -75,7 +87,8 @@ def test_stages_bit_exact_against_oracle(kw, upstream_tile_rule):
     np.testing.assert_array_equal(h["clamped"][vis].astype(bool), og["clamped"][vis].astype(bool))
     # S7-S8: identical sorted list (stable sort => deterministic), identical ranges
     assert h["n"] == f["num_rendered"]
-    np.testing.assert_array_equal(h["keys"], ob["keys"])
+    if not two_level:                      # the 64-bit tile<<32|depth keys only exist in global-sort mode
+        np.testing.assert_array_equal(h["keys"], ob["keys"])
     np.testing.assert_array_equal(h["point_list"], ob["vals"])
     np.testing.assert_array_equal(h["ranges"], ob["ranges"])
     # S9
