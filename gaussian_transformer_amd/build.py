@@ -49,6 +49,25 @@ def _newer(src_list, target) -> bool:
     return any(os.path.getmtime(s) > t for s in src_list)
 
 
+def build_variant(tag: str, defines, verbose: bool = False) -> str:
+    """Ablation build: every TU recompiled with extra -D flags into libgsr_hip_<tag>.so (scratch use)."""
+    cc = hipcc()
+    out = os.path.join(HERE, f"libgsr_hip_{tag}.so")
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    objs = []
+    odir = os.path.join(OBJ, tag)
+    os.makedirs(odir, exist_ok=True)
+    for src, extra in SOURCES.items():
+        o = os.path.join(odir, src.replace(".hip", ".o"))
+        cmd = [cc, "-c", os.path.join(CSRC, src), "-o", o] + COMMON + extra + [f"-D{d}" for d in defines]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(o)
+    subprocess.check_call([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs)
+    return out
+
+
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]

@@ -55,14 +55,14 @@ __device__ __forceinline__ float fold16(float a, float b) {
 template <int NPX>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, int nblocks_padded, int exact_cull) {
     constexpr int UNITS_PER_TILE = 4 / NPX;          // waves per tile
-    __shared__ float4 stage[4][64 * 3];
+    extern __shared__ __align__(16) float4 stage_dyn[];     // [waves per block][64 * 3]
     const int T = a.gridx * a.gridy;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int unit = xcd_band_unit(blockIdx.x, nblocks_padded) * 4 + wave;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int unit = xcd_band_unit(blockIdx.x, nblocks_padded) * wpb + wave;
     const int tile = unit / UNITS_PER_TILE, sub = unit % UNITS_PER_TILE;
     if (tile >= T) return;                            // wave-uniform
     const int tx = tile % a.gridx, ty = tile / a.gridx;
-    float4 *my = stage[wave];
+    float4 *my = stage_dyn + wave * (64 * 3);
     const float4 *rec4 = reinterpret_cast<const float4 *>(a.rec);
     const uint2 range = a.ranges[tile];
     const size_t HW = (size_t)a.W * a.H;
@@ -139,9 +139,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
             // v5..v7 = sum s*dx*dx, s*dx*dy, s*dy*dy (x -1/2 there), with s = o * G * dL/dalpha.
             float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
             const int pos = base + j;
-#pragma unroll
-            for (int q = 0; q < NPX; q++) {
-                if (!(bits & (1u << q))) continue;    // scalar branch: block q cannot be reached
+            // body for one 8x8 block; straight-line so that the blocks of one splat interleave (ILP)
+            auto block_body = [&](int q) __attribute__((always_inline)) {
                 const float dx = r0.x - fx[q], dy = r0.y - fy[q];
                 const float u = r0.z * dx + r0.w * dy, v = r1.x * dy + r0.w * dx;    // conic * d
                 const float qf = dx * u + dy * v;                                   // = -2 power
@@ -164,38 +163,59 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
                 v3 += sg * u; v4 += sg * v;
                 const float sx = sg * dx, sy = sg * dy;
                 v5 += sx * dx; v6 += sx * dy; v7 += sy * dy;
+            };
+#ifndef GSR_ABL_NOMATH
+            if (bits == (1u << NPX) - 1u) {           // scalar branch: every block reachable -> one basic block
+#pragma unroll
+                for (int q = 0; q < NPX; q++) block_body(q);
+            } else {
+#pragma unroll
+                for (int q = 0; q < NPX; q++)
+                    if (bits & (1u << q)) block_body(q);
             }
+#else
+            v0 = r0.x * fx[0]; v8 = r1.y;
+#endif
+#ifndef GSR_ABL_NOREDUCE
             float x0 = fold16(fold32(v0, v1), fold32(v2, v3));
             float x1 = fold16(fold32(v4, v5), fold32(v6, v7));
             float x2 = fold16(fold32(v8, 0.f), 0.f);
             x0 = row_allreduce(x0); x1 = row_allreduce(x1); x2 = row_allreduce(x2);
+#else
+            float x0 = v0 + v1 + v2 + v3, x1 = v4 + v5 + v6 + v7, x2 = v8;
+#endif
             const float sel = k16 == 0 ? x0 : (k16 == 1 ? x1 : x2);
             // opacity weight sum == 0 for every lane <=> no pixel blended this splat: skip the atomic
             const bool touched = __any(sel != 0.f);
+#ifndef GSR_ABL_NOATOMIC
             if (touched && slot >= 0) {
                 const uint32_t g = __float_as_uint(r2.w);
                 atomicAdd(a.acc + GSR_ACC_FLOATS * (size_t)g + slot, sel);
             }
+#else
+            if (touched && slot >= 0 && sel == 123.456f) a.acc[slot] = sel;   // keeps the chain alive, never stores
+#endif
         }
     }
 }
 
 template <int NPX>
-static hipError_t launch_bwd(const CompositeBwdArgs &a, int exact_cull, hipStream_t s) {
+static hipError_t launch_bwd(const CompositeBwdArgs &a, int exact_cull, int wpb, hipStream_t s) {
     const int T = a.gridx * a.gridy;
     const int units = T * (4 / NPX);
-    const int blocks = (units + 3) / 4;
+    const int blocks = (units + wpb - 1) / wpb;
     const int padded = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL(composite_bwd_kernel<NPX>, dim3(padded), dim3(256), 0, s, a, padded, exact_cull);
+    hipLaunchKernelGGL(composite_bwd_kernel<NPX>, dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4), s, a,
+                       padded, exact_cull);
     return hipGetLastError();
 }
 
-hipError_t launch_composite_bwd(const CompositeBwdArgs &a, int npx, int exact_cull, hipStream_t s) {
+hipError_t launch_composite_bwd(const CompositeBwdArgs &a, int npx, int exact_cull, int wpb, hipStream_t s) {
     if (a.gridx * a.gridy <= 0) return hipSuccess;
     switch (npx) {
-        case 1: return launch_bwd<1>(a, exact_cull, s);
-        case 2: return launch_bwd<2>(a, exact_cull, s);
-        default: return launch_bwd<4>(a, exact_cull, s);
+        case 1: return launch_bwd<1>(a, exact_cull, wpb, s);
+        case 2: return launch_bwd<2>(a, exact_cull, wpb, s);
+        default: return launch_bwd<4>(a, exact_cull, wpb, s);
     }
 }
 

@@ -28,16 +28,16 @@ __device__ __forceinline__ int xcd_band_unit_f(int b, int nblocks_padded) {
 template <int NPX>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int nblocks_padded, int exact_cull) {
     constexpr int UNITS_PER_TILE = 4 / NPX;
-    __shared__ float4 stage[4][64 * 3];
+    extern __shared__ __align__(16) float4 stage_dyn[];     // [waves per block][64 * 3]
     const int T = a.gridx * a.gridy;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int unit = xcd_band_unit_f(blockIdx.x, nblocks_padded) * 4 + wave;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int unit = xcd_band_unit_f(blockIdx.x, nblocks_padded) * wpb + wave;
     const int tile = unit / UNITS_PER_TILE, sub = unit % UNITS_PER_TILE;
     if (tile >= T) return;                            // wave-uniform
     const int tx = tile % a.gridx, ty = tile / a.gridx;
     const uint2 range = a.ranges[tile];
     const int n = (int)(range.y - range.x);
-    float4 *my = stage[wave];
+    float4 *my = stage_dyn + wave * (64 * 3);
     const float4 *rec4 = reinterpret_cast<const float4 *>(a.rec);
 
     float fx[NPX], fy[NPX], Tr[NPX], C0[NPX], C1[NPX], C2[NPX];
@@ -132,21 +132,22 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
 }
 
 template <int NPX>
-static hipError_t launch_fwd(const CompositeArgs &a, int exact_cull, hipStream_t s) {
+static hipError_t launch_fwd(const CompositeArgs &a, int exact_cull, int wpb, hipStream_t s) {
     const int T = a.gridx * a.gridy;
     const int units = T * (4 / NPX);
-    const int blocks = (units + 3) / 4;
+    const int blocks = (units + wpb - 1) / wpb;
     const int padded = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL(composite_fwd_kernel<NPX>, dim3(padded), dim3(256), 0, s, a, padded, exact_cull);
+    hipLaunchKernelGGL(composite_fwd_kernel<NPX>, dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4), s, a,
+                       padded, exact_cull);
     return hipGetLastError();
 }
 
-hipError_t launch_composite_fwd(const CompositeArgs &a, int npx, int exact_cull, hipStream_t s) {
+hipError_t launch_composite_fwd(const CompositeArgs &a, int npx, int exact_cull, int wpb, hipStream_t s) {
     if (a.gridx * a.gridy <= 0) return hipSuccess;
     switch (npx) {
-        case 1: return launch_fwd<1>(a, exact_cull, s);
-        case 2: return launch_fwd<2>(a, exact_cull, s);
-        default: return launch_fwd<4>(a, exact_cull, s);
+        case 1: return launch_fwd<1>(a, exact_cull, wpb, s);
+        case 2: return launch_fwd<2>(a, exact_cull, wpb, s);
+        default: return launch_fwd<4>(a, exact_cull, wpb, s);
     }
 }
 

@@ -19,6 +19,7 @@ static std::atomic<int> g_profiling{0};
 static std::atomic<int> g_exact_cull{1};
 static std::atomic<int> g_bwd_npx{2};
 static std::atomic<int> g_fwd_npx{2};
+static std::atomic<int> g_wpb{1};           // waves per workgroup of the compositing kernels (waves are independent)
 static std::atomic<int> g_two_level_sort{1};   // 1: rocPRIM by tile + per-tile LDS depth sort; 0: one global 64-bit-key sort      // same for the forward compositing kernel      // 8x8 pixel blocks per wave in the reverse compositing kernel (1, 2 or 4)   // output-invariant exact splat-vs-tile culling (gsr_set_option)
 static float g_stage_ms[GSR_NUM_STAGES] = {0};
 static const char *const k_stage_names[GSR_NUM_STAGES] = {
@@ -143,6 +144,10 @@ const char *gsr_last_error(void) { return g_err; }
 int32_t gsr_set_option(const char *name, int32_t value) {
     if (name && !strcmp(name, "exact_tile_cull")) { g_exact_cull.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "two_level_sort")) { g_two_level_sort.store(value ? 1 : 0); return GSR_OK; }
+    if (name && !strcmp(name, "composite_waves_per_block")) {
+        if (value != 1 && value != 2 && value != 4) return fail(GSR_ERR_INVALID_ARGUMENT, "composite_waves_per_block must be 1, 2 or 4");
+        g_wpb.store(value); return GSR_OK;
+    }
     if (name && !strcmp(name, "fwd_blocks_per_wave")) {
         if (value != 1 && value != 2 && value != 4) return fail(GSR_ERR_INVALID_ARGUMENT, "fwd_blocks_per_wave must be 1, 2 or 4");
         g_fwd_npx.store(value); return GSR_OK;
@@ -158,6 +163,7 @@ int32_t gsr_get_option(const char *name, int32_t *value) {
     if (name && value && !strcmp(name, "bwd_blocks_per_wave")) { *value = g_bwd_npx.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "fwd_blocks_per_wave")) { *value = g_fwd_npx.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "two_level_sort")) { *value = g_two_level_sort.load(); return GSR_OK; }
+    if (name && value && !strcmp(name, "composite_waves_per_block")) { *value = g_wpb.load(); return GSR_OK; }
     return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_get_option: unknown option '%s'", name ? name : "(null)");
 }
 
@@ -274,7 +280,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     CompositeArgs ca;
     ca.W = W; ca.H = H; ca.gridx = gridx; ca.gridy = gridy; ca.ranges = im.ranges; ca.point_list = b.point_list;
     ca.rec = g.rec; ca.bg = bg; ca.final_T = im.final_T; ca.n_contrib = im.n_contrib; ca.out_color = out_color;
-    HIP_TRY(launch_composite_fwd(ca, g_fwd_npx.load(), pa.exact_cull, s), "composite launch");
+    HIP_TRY(launch_composite_fwd(ca, g_fwd_npx.load(), pa.exact_cull, g_wpb.load(), s), "composite launch");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "composite");
     tm.mark(-1);
     tm.finish(10);
@@ -325,7 +331,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
         ca.W = W; ca.H = H; ca.gridx = gridx; ca.gridy = gridy; ca.ranges = im.ranges; ca.point_list = b.point_list;
         ca.rec = g.rec; ca.bg = bg; ca.final_T = im.final_T; ca.n_contrib = im.n_contrib; ca.dL_dpix = dL_dpix;
         ca.acc = (float *)bwd_ws;
-        HIP_TRY(launch_composite_bwd(ca, g_bwd_npx.load(), g_exact_cull.load(), s), "composite backward launch");
+        HIP_TRY(launch_composite_bwd(ca, g_bwd_npx.load(), g_exact_cull.load(), g_wpb.load(), s), "composite backward launch");
         if (debug) HIP_TRY(hipStreamSynchronize(s), "composite backward");
     }
     tm.mark(9);

@@ -92,7 +92,7 @@ struct CompositeArgs {
     uint32_t *n_contrib;
     float *out_color;
 };
-hipError_t launch_composite_fwd(const CompositeArgs &a, int npx, int exact_cull, hipStream_t s);
+hipError_t launch_composite_fwd(const CompositeArgs &a, int npx, int exact_cull, int waves_per_block, hipStream_t s);
 
 struct CompositeBwdArgs {
     int W, H, gridx, gridy;
@@ -105,7 +105,7 @@ struct CompositeBwdArgs {
     const float *dL_dpix;
     float *acc;   // [P][16], zeroed
 };
-hipError_t launch_composite_bwd(const CompositeBwdArgs &a, int npx, int exact_cull, hipStream_t s);
+hipError_t launch_composite_bwd(const CompositeBwdArgs &a, int npx, int exact_cull, int waves_per_block, hipStream_t s);
 
 struct PergaussBwdArgs {
     int P, D, M, W, H;

@@ -124,6 +124,8 @@ int32_t gsr_debug_read_image_state(gsr_stream_t stream, int32_t W, int32_t H, co
  *   "two_level_sort" (default 1): order the pairs with a stable rocPRIM radix sort on the TILE id only
  *        and finish each tile's slice with an in-LDS sort on (depth bits, Gaussian id); identical
  *        resulting order to 0 = one global radix sort on tile<<32|depth.  Speed only.
+ *   "composite_waves_per_block" (1, 2 or 4; default 1): wave64s per workgroup of the compositing
+ *        kernels.  The waves never synchronise, so 1 lets every wave retire (and be replaced) alone.
  *   "fwd_blocks_per_wave", "bwd_blocks_per_wave" (1, 2 or 4; default 2): 8x8 pixel blocks one
  *        wave64 of the forward / reverse compositing kernel owns (4 = a whole 16x16 tile).  Speed only. */
 int32_t gsr_set_option(const char *name, int32_t value);
