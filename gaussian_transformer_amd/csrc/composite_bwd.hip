@@ -55,14 +55,15 @@ __device__ __forceinline__ float fold16(float a, float b) {
 template <int NPX>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, int nblocks_padded, int exact_cull) {
     constexpr int UNITS_PER_TILE = 4 / NPX;          // waves per tile
-    extern __shared__ __align__(16) float4 stage_dyn[];     // [waves per block][64 * 3]
+    extern __shared__ __align__(16) float4 stage_dyn[];     // per wave: 64 records x 3 float4, then 16 x 64 floats of reduction scratch
     const int T = a.gridx * a.gridy;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     const int unit = xcd_band_unit(blockIdx.x, nblocks_padded) * wpb + wave;
     const int tile = unit / UNITS_PER_TILE, sub = unit % UNITS_PER_TILE;
     if (tile >= T) return;                            // wave-uniform
     const int tx = tile % a.gridx, ty = tile / a.gridx;
-    float4 *my = stage_dyn + wave * (64 * 3);
+    float4 *my = stage_dyn + wave * (64 * 3 + 16 * 16);
+    float *red = reinterpret_cast<float *>(my + 64 * 3);   // [value 0..8][lane 0..63]
     const float4 *rec4 = reinterpret_cast<const float4 *>(a.rec);
     const uint2 range = a.ranges[tile];
     const size_t HW = (size_t)a.W * a.H;
@@ -99,14 +100,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
     for (int m = 32; m > 0; m >>= 1) max_last = max(max_last, __shfl_xor(max_last, m));
     if (max_last == 0) return;                        // wave-uniform
 
-    // which accumulator slot this lane's reduced value belongs to (see the fold order below)
-    //   x0 rows -> (v0, v2, v1, v3) in lanes 16r,  x1 rows -> (v4, v6, v5, v7) in lanes 16r+1,  x2 row 0 -> v8 in lane 2
-    const int row = lane >> 4, k16 = lane & 15;
-    const int rowperm = ((row & 1) << 1) | (row >> 1);          // 0,2,1,3
-    int slot = -1;
-    if (k16 == 0) slot = rowperm;
-    else if (k16 == 1) slot = 4 + rowperm;
-    else if (lane == 2) slot = 8;
+    // Cross-lane reduction through LDS (the LDS pipe is idle otherwise, the VALU is the bottleneck):
+    // every lane stores its 9 partial sums as red[value][lane]; lane 4*value + part then adds the 16
+    // floats red[value][16*part .. 16*part+15] (4 x ds_read_b128), two DPP steps fold the 4 parts, and
+    // lanes 0,4,...,32 hold the nine totals: ONE 9-lane global_atomic_add_f32 per (wave, splat).
+    const int rvalue = lane >> 2, rpart = lane & 3;
+    const float4 *red_rd = reinterpret_cast<const float4 *>(red + (rvalue < 9 ? rvalue : 0) * 64 + rpart * 16);
+    const bool red_lane = rvalue < 9;
+    const int slot = (red_lane && rpart == 0) ? rvalue : -1;
 
     for (int base = ((max_last - 1) >> 6) << 6; base >= 0; base -= 64) {
         const int cnt = min(64, max_last - base);
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
             // v5..v7 = sum s*dx*dx, s*dx*dy, s*dy*dy (x -1/2 there), with s = o * G * dL/dalpha.
             float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
             const int pos = base + j;
+            bool any_ok = false;
             // body for one 8x8 block; straight-line so that the blocks of one splat interleave (ILP)
             auto block_body = [&](int q) __attribute__((always_inline)) {
                 const float dx = r0.x - fx[q], dy = r0.y - fy[q];
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
                 const float G = __builtin_amdgcn_exp2f(qf * (-0.5f * LOG2E));
                 const float alpha = fminf(GSR_ALPHA_MAX, r1.y * G);
                 const bool ok = (pos < last[q]) && !(qf < 0.f) && !(alpha < GSR_ALPHA_MIN);
+                any_ok = any_ok || ok;
                 const float a_ok = ok ? alpha : 0.f;
                 const float inv = __builtin_amdgcn_rcpf(1.f - a_ok);
                 const float Tk = Tr[q] * inv;                        // transmittance in front of this splat
@@ -177,16 +180,25 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
             v0 = r0.x * fx[0]; v8 = r1.y;
 #endif
 #ifndef GSR_ABL_NOREDUCE
-            float x0 = fold16(fold32(v0, v1), fold32(v2, v3));
-            float x1 = fold16(fold32(v4, v5), fold32(v6, v7));
-            float x2 = fold16(fold32(v8, 0.f), 0.f);
-            x0 = row_allreduce(x0); x1 = row_allreduce(x1); x2 = row_allreduce(x2);
+            if (!__any(any_ok)) continue;             // wave-uniform: no pixel of this wave blends the splat
+            red[0 * 64 + lane] = v0; red[1 * 64 + lane] = v1; red[2 * 64 + lane] = v2;
+            red[3 * 64 + lane] = v3; red[4 * 64 + lane] = v4; red[5 * 64 + lane] = v5;
+            red[6 * 64 + lane] = v6; red[7 * 64 + lane] = v7; red[8 * 64 + lane] = v8;
+            __builtin_amdgcn_wave_barrier();
+            float sel = 0.f;
+            if (red_lane) {
+                const float4 p0 = red_rd[0], p1 = red_rd[1], p2 = red_rd[2], p3 = red_rd[3];
+                sel = ((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w)) +
+                      (((p2.x + p2.y) + (p2.z + p2.w)) + ((p3.x + p3.y) + (p3.z + p3.w)));
+            }
+            __builtin_amdgcn_wave_barrier();
+            sel = dpp_add<0xB1>(sel);   // quad_perm [1,0,3,2]
+            sel = dpp_add<0x4E>(sel);   // quad_perm [2,3,0,1]
+            const bool touched = true;
 #else
-            float x0 = v0 + v1 + v2 + v3, x1 = v4 + v5 + v6 + v7, x2 = v8;
+            float sel = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7 + v8;
+            const bool touched = true;
 #endif
-            const float sel = k16 == 0 ? x0 : (k16 == 1 ? x1 : x2);
-            // opacity weight sum == 0 for every lane <=> no pixel blended this splat: skip the atomic
-            const bool touched = __any(sel != 0.f);
 #ifndef GSR_ABL_NOATOMIC
             if (touched && slot >= 0) {
                 const uint32_t g = __float_as_uint(r2.w);
@@ -205,7 +217,7 @@ static hipError_t launch_bwd(const CompositeBwdArgs &a, int exact_cull, int wpb,
     const int units = T * (4 / NPX);
     const int blocks = (units + wpb - 1) / wpb;
     const int padded = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL(composite_bwd_kernel<NPX>, dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4), s, a,
+    hipLaunchKernelGGL(composite_bwd_kernel<NPX>, dim3(padded), dim3(64 * wpb), (size_t)wpb * (64 * 3 + 16 * 16) * sizeof(float4), s, a,
                        padded, exact_cull);
     return hipGetLastError();
 }
