@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void tile_depth_sort_kernel(const uint2 *__res
     const uint32_t tid = threadIdx.x;
     const uint64_t *src = dvals + r.x;
     if (n == 1) { if (tid == 0) point_list[r.x] = (uint32_t)src[0]; return; }
-    uint32_t m = 2;
+    uint32_t m = 4;
     while (m < n) m <<= 1;
     if (LAST && n > (uint32_t)CAP) {
         // rare (> 16384 pairs in one tile): rank sort, keys streamed through LDS in CAP-sized chunks.
@@ -101,18 +101,79 @@ __global__ __launch_bounds__(256) void tile_depth_sort_kernel(const uint2 *__res
         for (uint32_t i = tid; i < n; i += 256) point_list[r.x + scratch[r.x + i]] = (uint32_t)src[i];
         return;
     }
+    if (n == 2) {
+        if (tid == 0) {
+            const uint64_t a = src[0], bb = src[1];
+            point_list[r.x] = (uint32_t)(a < bb ? a : bb);
+            point_list[r.x + 1] = (uint32_t)(a < bb ? bb : a);
+        }
+        return;
+    }
+    // ---- bitonic network, m = next power of two >= n (>= 4), padded with +inf ----
+    // Each thread owns groups of 4 consecutive elements: the j = 2 and j = 1 steps of every level run in
+    // registers (one 32-byte LDS read + write per group instead of two passes).  Each wave owns whole
+    // 256-element blocks, so steps with j <= 128 need no workgroup barrier (LDS operations of one wave
+    // execute in order); only the cross-block steps (j >= 256: 1 for m = 512, 3 for m = 1024, ...) do.
     for (uint32_t i = tid; i < m; i += 256) lds_keys[i] = i < n ? src[i] : ~0ull;
     __syncthreads();
-    for (uint32_t k = 2; k <= m; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t p = tid; p < (m >> 1); p += 256) {
-                const uint32_t i = ((p / j) * (j << 1)) + (p % j), l = i + j;     // j is a power of two
-                const bool asc = (i & k) == 0;
-                const uint64_t a = lds_keys[i], bb = lds_keys[l];
-                if ((a > bb) == asc) { lds_keys[i] = bb; lds_keys[l] = a; }
-            }
-            __syncthreads();
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    const uint32_t bsize = m < 256u ? m : 256u;            // elements per block
+    const uint32_t nblk = m / bsize;
+    auto cex = [](uint64_t &a, uint64_t &bb, bool asc) __attribute__((always_inline)) {
+        const bool sw = (a > bb) == asc;
+        const uint64_t lo = sw ? bb : a, hi = sw ? a : bb;
+        a = lo; bb = hi;
+    };
+    using u64x2 = uint64_t __attribute__((ext_vector_type(2)));
+    // phase 0: levels k = 2 and k = 4 == sort every 4-group, ascending iff bit 2 of its base index is 0
+    for (uint32_t b = wave; b < nblk; b += 4)
+        for (uint32_t q = lane; q < (bsize >> 2); q += 64) {
+            const uint32_t i0 = b * 256 + q * 4;
+            u64x2 *p = reinterpret_cast<u64x2 *>(lds_keys + i0);
+            u64x2 lo2 = p[0], hi2 = p[1];
+            uint64_t e0 = lo2.x, e1 = lo2.y, e2 = hi2.x, e3 = hi2.y;
+            const bool asc = (m == 4u) || ((i0 & 4u) == 0u);
+            cex(e0, e1, asc); cex(e2, e3, asc); cex(e0, e2, asc); cex(e1, e3, asc); cex(e1, e2, asc);
+            lo2.x = e0; lo2.y = e1; hi2.x = e2; hi2.y = e3;
+            p[0] = lo2; p[1] = hi2;
         }
+    for (uint32_t k = 8; k <= m; k <<= 1) {
+        for (uint32_t j = k >> 1; j >= 4; j >>= 1) {
+            const uint32_t sh = 31u - (uint32_t)__builtin_clz(j);          // log2 j
+            if (j >= 256u) {                                               // cross-block step
+                __syncthreads();
+                for (uint32_t p = tid; p < (m >> 1); p += 256) {
+                    const uint32_t i = ((p >> sh) << (sh + 1)) + (p & (j - 1)), l = i + j;
+                    uint64_t a = lds_keys[i], bb = lds_keys[l];
+                    cex(a, bb, (i & k) == 0u);
+                    lds_keys[i] = a; lds_keys[l] = bb;
+                }
+                __syncthreads();
+            } else {                                                       // inside this wave's blocks
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t b = wave; b < nblk; b += 4)
+                    for (uint32_t lp = lane; lp < (bsize >> 1); lp += 64) {
+                        const uint32_t i = b * 256 + ((lp >> sh) << (sh + 1)) + (lp & (j - 1)), l = i + j;
+                        uint64_t a = lds_keys[i], bb = lds_keys[l];
+                        cex(a, bb, (i & k) == 0u);
+                        lds_keys[i] = a; lds_keys[l] = bb;
+                    }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t b = wave; b < nblk; b += 4)                          // j = 2 and j = 1 in registers
+            for (uint32_t q = lane; q < (bsize >> 2); q += 64) {
+                const uint32_t i0 = b * 256 + q * 4;
+                u64x2 *p = reinterpret_cast<u64x2 *>(lds_keys + i0);
+                u64x2 lo2 = p[0], hi2 = p[1];
+                uint64_t e0 = lo2.x, e1 = lo2.y, e2 = hi2.x, e3 = hi2.y;
+                const bool asc = (i0 & k) == 0u;
+                cex(e0, e2, asc); cex(e1, e3, asc); cex(e0, e1, asc); cex(e2, e3, asc);
+                lo2.x = e0; lo2.y = e1; hi2.x = e2; hi2.y = e3;
+                p[0] = lo2; p[1] = hi2;
+            }
+    }
+    __syncthreads();
     for (uint32_t i = tid; i < n; i += 256) point_list[r.x + i] = (uint32_t)lds_keys[i];
 }
 
