@@ -36,8 +36,9 @@ def algorithmic_bytes(P, N, HW, K, M):
         "fwd.preprocess": (44 + 12 * K + 75) * P,
         "fwd.scan": 8 * P,
         "fwd.emit_keys": 20 * P + 12 * N,
-        "fwd.sort": 24 * N,
+        "fwd.sort": 24 * N,               # stable radix sort of the pairs by tile id (one read + one write)
         "fwd.ranges": 8 * N,
+        "fwd.tile_depth_sort": 12 * N,    # per-tile (depth, id) ordering in LDS: read 8 B, write 4 B per pair
         "fwd.composite": 40 * N + 20 * HW,
         "bwd.zero_acc": 0,
         "bwd.composite": 40 * N + 20 * HW + 36 * P,
@@ -156,6 +157,14 @@ def main():
         empty = torch.empty(0, device=dev)
         N = get_backend().forward(rs, means3D.detach(), shs.detach(), empty, opac.detach(), scales.detach(),
                                   rots.detach(), empty)[0]
+        # pairs upstream's rule (every tile of the 3-sigma bounding square) would have emitted
+        _lib.set_option("exact_tile_cull", 0)
+        N_ref_rule = get_backend().forward(rs, means3D.detach(), shs.detach(), empty, opac.detach(), scales.detach(),
+                                           rots.detach(), empty)[0]
+        _lib.set_option("exact_tile_cull", 1)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            _lib.set_option(k, int(v))
     K = (D + 1) ** 2
     HW = W * H
     ab = algorithmic_bytes(P, N, HW, K, M)
@@ -209,7 +218,8 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.config, "gaussians": P, "width": W, "height": H, "sh_degree": D,
-                       "num_rendered_pairs": int(N), "cameras_per_step": world,
+                       "num_rendered_pairs": int(N), "pairs_under_reference_tile_rule": int(N_ref_rule),
+                       "cameras_per_step": world,
                        "parallelism": f"dp{world} (one camera per GPU" + (", RCCL all-reduce of gradients)" if world > 1 else ")")},
             "roofline": roofline,
             "cpu_baseline": cpu,

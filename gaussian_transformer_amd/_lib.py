@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(_HERE, "libgsr_hip.so")   # GSR_LIB_PATH: ablation builds (scripts/)
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
-GSR_NUM_STAGES = 12
+GSR_NUM_STAGES = 13
 
 _p = C.c_void_p
 _i32 = C.c_int32

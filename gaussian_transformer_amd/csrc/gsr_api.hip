@@ -23,8 +23,8 @@ static std::atomic<int> g_wpb{1};           // waves per workgroup of the compos
 static std::atomic<int> g_two_level_sort{1};   // 1: rocPRIM by tile + per-tile LDS depth sort; 0: one global 64-bit-key sort      // same for the forward compositing kernel      // 8x8 pixel blocks per wave in the reverse compositing kernel (1, 2 or 4)   // output-invariant exact splat-vs-tile culling (gsr_set_option)
 static float g_stage_ms[GSR_NUM_STAGES] = {0};
 static const char *const k_stage_names[GSR_NUM_STAGES] = {
-    "fwd.preprocess", "fwd.scan", "fwd.readback_N", "fwd.emit_keys", "fwd.sort", "fwd.ranges", "fwd.composite",
-    "bwd.zero_acc", "bwd.composite", "bwd.pergauss", "fwd.total", "bwd.total"};
+    "fwd.preprocess", "fwd.scan", "fwd.readback_N", "fwd.emit_keys", "fwd.sort", "fwd.ranges", "fwd.tile_depth_sort",
+    "fwd.composite", "bwd.zero_acc", "bwd.composite", "bwd.pergauss", "fwd.total", "bwd.total"};
 
 static int fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -272,18 +272,19 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     tm.mark(5);
     HIP_TRY(launch_ranges(b, im, N, T, two_level, s), "tile ranges");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "tile ranges");
+    tm.mark(6);
     if (two_level && N > 0) {
         HIP_TRY(launch_tile_depth_sort(b, im, T, s), "per-tile depth sort");
         if (debug) HIP_TRY(hipStreamSynchronize(s), "per-tile depth sort");
     }
-    tm.mark(6);
+    tm.mark(7);
     CompositeArgs ca;
     ca.W = W; ca.H = H; ca.gridx = gridx; ca.gridy = gridy; ca.ranges = im.ranges; ca.point_list = b.point_list;
     ca.rec = g.rec; ca.bg = bg; ca.final_T = im.final_T; ca.n_contrib = im.n_contrib; ca.out_color = out_color;
     HIP_TRY(launch_composite_fwd(ca, g_fwd_npx.load(), pa.exact_cull, g_wpb.load(), s), "composite launch");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "composite");
     tm.mark(-1);
-    tm.finish(10);
+    tm.finish(11);
     return GSR_OK;
 }
 
@@ -323,9 +324,9 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     const int gridx = grid_dim(W), gridy = grid_dim(H);
 
     StageTimer tm(s, g_profiling.load() != 0);
-    tm.mark(7);
-    HIP_TRY(hipMemsetAsync(bwd_ws, 0, acc_bytes, s), "zero accumulators");
     tm.mark(8);
+    HIP_TRY(hipMemsetAsync(bwd_ws, 0, acc_bytes, s), "zero accumulators");
+    tm.mark(9);
     if (R > 0) {
         CompositeBwdArgs ca;
         ca.W = W; ca.H = H; ca.gridx = gridx; ca.gridy = gridy; ca.ranges = im.ranges; ca.point_list = b.point_list;
@@ -334,7 +335,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
         HIP_TRY(launch_composite_bwd(ca, g_bwd_npx.load(), g_exact_cull.load(), g_wpb.load(), s), "composite backward launch");
         if (debug) HIP_TRY(hipStreamSynchronize(s), "composite backward");
     }
-    tm.mark(9);
+    tm.mark(10);
     PergaussBwdArgs pa;
     pa.P = P; pa.D = D; pa.M = M; pa.W = W; pa.H = H; pa.means3D = means3D; pa.shs = shs; pa.colors_precomp = colors_precomp;
     pa.scales = scales; pa.rotations = rotations; pa.cov3D_precomp = cov3D_precomp; pa.viewmatrix = viewmatrix;
@@ -345,7 +346,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     HIP_TRY(launch_pergauss_bwd(pa, s), "per-Gaussian backward launch");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "per-Gaussian backward");
     tm.mark(-1);
-    tm.finish(11);
+    tm.finish(12);
     return GSR_OK;
 }
 

@@ -134,7 +134,7 @@ int32_t gsr_get_option(const char *name, int32_t *value);
 /* Per-stage timing of the last gsr_forward / gsr_backward of this process, milliseconds,
  * measured with hipEvents on `stream` when profiling was enabled by gsr_set_profiling(1).
  * names: array of GSR_NUM_STAGES const char*; ms: array of GSR_NUM_STAGES floats (host). */
-#define GSR_NUM_STAGES 12
+#define GSR_NUM_STAGES 13
 int32_t gsr_set_profiling(int32_t enable);
 int32_t gsr_get_stage_times(const char **names, float *ms);
 

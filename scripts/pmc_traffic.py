@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""HBM traffic per stage and per render from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+(scripts/pmc_passes.sh).  Correction per MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are in
+KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is
+exact for 16-B streaming stores and float atomics.  (Gather-type reads are uncalibrated: the doubled
+figure is an upper bound for them.)   usage: pmc_traffic.py <pmc dir> <tag> <out.json>"""
+import csv, glob, json, os, sys, collections
+
+d, tag, out = sys.argv[1], sys.argv[2], sys.argv[3]
+STAGES = [("composite_bwd_kernel", "bwd.composite"), ("composite_fwd_kernel", "fwd.composite"),
+          ("preprocess_fwd_kernel", "fwd.preprocess"), ("pergauss_bwd_kernel", "bwd.pergauss"),
+          ("emit_keys_kernel", "fwd.emit_keys"), ("tile_ranges", "fwd.ranges"), ("tile_depth_sort_kernel", "fwd.tile_depth_sort"),
+          ("scan", "fwd.scan"), ("onesweep", "fwd.sort"), ("histogram", "fwd.sort"), ("radix_sort", "fwd.sort"), ("rocprim", "fwd.sort")]
+tot = collections.defaultdict(lambda: collections.defaultdict(float))
+steps = 0
+for f in sorted(glob.glob(os.path.join(d, f"{tag}_pass*_counter_collection.csv"))):
+    rows = list(csv.DictReader(open(f)))
+    if not rows or rows[0]["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_ATOMIC_sum"):
+        continue
+    cname = next(r["Counter_Name"] for r in rows if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"))
+    n_fwd = sum(1 for r in rows if "composite_fwd_kernel" in r["Kernel_Name"] and r["Counter_Name"] == cname)
+    n_bwd = sum(1 for r in rows if "composite_bwd_kernel" in r["Kernel_Name"] and r["Counter_Name"] == cname)
+    for r in rows:
+        if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
+            continue
+        for pat, st in STAGES:
+            if pat in r["Kernel_Name"]:
+                tot[st][r["Counter_Name"]] += float(r["Counter_Value"]) / max(n_bwd if st.startswith("bwd.") else n_fwd, 1)
+                break
+res = {}
+for st, c in tot.items():
+    rd = 2.0 * c.get("FETCH_SIZE", 0.0) * 1024.0
+    wr = c.get("WRITE_SIZE", 0.0) * 1024.0
+    res[st] = int(rd + wr)
+    res[st + ".read"] = int(rd); res[st + ".write"] = int(wr)
+res["per_render_total"] = int(sum(v for k, v in res.items() if "." in k and k.count(".") == 1))
+json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+print(json.dumps(res, indent=1, sort_keys=True))
