@@ -34,11 +34,10 @@ def algorithmic_bytes(P, N, HW, K, M):
     its inputs once and writes its outputs once; the sort counts one read + one write of the pairs."""
     return {
         "fwd.preprocess": (44 + 12 * K + 75) * P,
-        "fwd.scan": 8 * P,
+        "fwd.depth_order+scan": 16 * P + 8 * P,   # Gaussians sorted by depth (8 B read + 8 B written) + scan (SURVEY: 8 P)
         "fwd.emit_keys": 20 * P + 12 * N,
-        "fwd.sort": 24 * N,               # stable radix sort of the pairs by tile id (one read + one write)
+        "fwd.sort": 24 * N,               # SURVEY's figure (one read + one write of 12-byte pairs); ours moves 8-byte pairs
         "fwd.ranges": 8 * N,
-        "fwd.tile_depth_sort": 12 * N,    # per-tile (depth, id) ordering in LDS: read 8 B, write 4 B per pair
         "fwd.composite": 40 * N + 20 * HW,
         "bwd.zero_acc": 0,
         "bwd.composite": 40 * N + 20 * HW + 36 * P,

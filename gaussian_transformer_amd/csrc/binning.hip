@@ -43,15 +43,51 @@ hipError_t launch_sort(const BinningView &b, int64_t N, int bits, hipStream_t s)
                                      (unsigned)bits, s, false);
 }
 
-// ---- two-level sort: rocPRIM orders the pairs by TILE only (stable, 2 onesweep passes over
-// ceil(log2 T) bits instead of 5 over 32+log2 T), then one workgroup per tile orders its
-// contiguous slice by (depth bits, Gaussian id) in LDS.  Within a tile the stable tile sort keeps
-// emission order = ascending Gaussian id, so (depth, id) reproduces exactly the order of a global
-// stable sort on tile<<32|depth.
+// ---- two-level sort.  Level 1 sorts the P GAUSSIANS by depth (stable radix sort of 32-bit depth bits,
+// value = Gaussian id): 8 bytes x P instead of 12 bytes x N.  Key emission then walks the Gaussians in
+// that order, so the pairs leave in global depth order, and level 2 -- a STABLE rocPRIM radix sort of
+// (tile id, Gaussian id) pairs on the ceil(log2 T) tile bits only (2 onesweep passes moving 8 bytes per
+// pair, instead of 5 passes over 32+log2 T bits moving 12) -- keeps every tile's slice in depth order.
+// Ties in depth keep ascending Gaussian id (both sorts are stable), i.e. exactly the order of one global
+// stable sort on tile<<32|depth with emission in id order.
+// Onesweep for every size: rocPRIM's default switches to a merge sort below 1 M items, which costs
+// ~20 small launches (~140 us) for 1 M Gaussians against ~5 launches for the radix passes.
+using DepthSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+
+hipError_t depth_sort_temp_bytes(int P, size_t *bytes) {
+    size_t tb = 0;
+    hipError_t e = rocprim::radix_sort_pairs<DepthSortConfig>(nullptr, tb, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                             rocprim::counting_iterator<uint32_t>(0), (uint32_t *)nullptr,
+                                             (size_t)(P > 0 ? P : 1), 0u, 32u, (hipStream_t)0, false);
+    *bytes = tb;
+    return e;
+}
+
+// Level 1: Gaussian ids in (depth, id) order.  Culled Gaussians carry depth 0 and emit no pairs, so
+// their position is irrelevant.  (Running this on a helper stream beside preprocess was tried: the
+// radix passes just queue behind preprocess's resident workgroups, no overlap -- kept on one stream.)
+hipError_t launch_depth_sort(const GeomView &g, int P, hipStream_t s) {
+    size_t tb = g.dsort_temp_bytes;
+    return rocprim::radix_sort_pairs<DepthSortConfig>(g.dsort_temp, tb, reinterpret_cast<const uint32_t *>(g.depth), g.depth_sorted,
+                                                      rocprim::counting_iterator<uint32_t>(0), g.perm, (size_t)P, 0u, 32u, s, false);
+}
+
+struct TilesOf {
+    const uint32_t *tiles;
+    __host__ __device__ uint32_t operator()(uint32_t g) const { return tiles[g]; }
+};
+
+// perm = Gaussian ids in (depth, id) order (launch_depth_sort); offsets[i] = inclusive scan of tiles[perm[i]]
+hipError_t launch_ordered_scan(const GeomView &g, int P, hipStream_t s) {
+    size_t sb = g.scan_temp_bytes;
+    auto in = rocprim::make_transform_iterator(static_cast<const uint32_t *>(g.perm), TilesOf{g.tiles});
+    return rocprim::inclusive_scan(g.scan_temp, sb, in, g.offsets, (size_t)P, rocprim::plus<uint32_t>(), s, false);
+}
+
 hipError_t sort2_temp_bytes(int64_t N, int tile_bits, size_t *bytes) {
     size_t tb = 0;
     hipError_t e = rocprim::radix_sort_pairs(nullptr, tb, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                             (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                             (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                              (size_t)(N > 0 ? N : 1), 0u, (unsigned)tile_bits, (hipStream_t)0, false);
     *bytes = tb;
     return e;
@@ -60,151 +96,26 @@ hipError_t sort2_temp_bytes(int64_t N, int tile_bits, size_t *bytes) {
 hipError_t launch_sort2_by_tile(const BinningView &b, int64_t N, int tile_bits, hipStream_t s) {
     size_t tb = b.sort_temp_bytes;
     return rocprim::radix_sort_pairs(b.sort_temp, tb, (const uint32_t *)b.tkeys_unsorted, b.tkeys_sorted,
-                                     (const uint64_t *)b.dvals_unsorted, b.dvals_sorted, (size_t)N, 0u,
+                                     (const uint32_t *)b.ids_unsorted, b.point_list, (size_t)N, 0u,
                                      (unsigned)tile_bits, s, false);
 }
 
-// One workgroup per tile: bitonic sort of the tile's (depth<<32 | id) words in LDS, ids out.
-// CAP = LDS capacity in elements; the kernel instance handles tiles with LO < n <= CAP.  The last
-// instance (CAP = 16384) also takes larger tiles through a (slow) in-place global-memory path.
-template <int CAP, int LO, bool LAST>
-__global__ __launch_bounds__(256) void tile_depth_sort_kernel(const uint2 *__restrict__ ranges,
-                                                              uint64_t *__restrict__ dvals,
-                                                              uint32_t *__restrict__ point_list,
-                                                              uint32_t *__restrict__ scratch) {
-    extern __shared__ __align__(16) uint64_t lds_keys[];
-    const uint2 r = ranges[blockIdx.x];
-    const uint32_t n = r.y - r.x;
-    if (n <= (uint32_t)LO || (!LAST && n > (uint32_t)CAP)) return;     // workgroup-uniform
-    const uint32_t tid = threadIdx.x;
-    const uint64_t *src = dvals + r.x;
-    if (n == 1) { if (tid == 0) point_list[r.x] = (uint32_t)src[0]; return; }
-    uint32_t m = 4;
-    while (m < n) m <<= 1;
-    if (LAST && n > (uint32_t)CAP) {
-        // rare (> 16384 pairs in one tile): rank sort, keys streamed through LDS in CAP-sized chunks.
-        // All keys of a tile are distinct (the id is part of the key), so rank = #smaller keys.
-        for (uint32_t i = tid; i < n; i += 256) scratch[r.x + i] = 0u;
-        for (uint32_t c0 = 0; c0 < n; c0 += CAP) {
-            const uint32_t cn = min((uint32_t)CAP, n - c0);
-            __syncthreads();
-            for (uint32_t i = tid; i < cn; i += 256) lds_keys[i] = src[c0 + i];
-            __syncthreads();
-            for (uint32_t i = tid; i < n; i += 256) {
-                const uint64_t mine = src[i];
-                uint32_t less = 0;
-                for (uint32_t t = 0; t < cn; t++) less += lds_keys[t] < mine ? 1u : 0u;
-                scratch[r.x + i] += less;
-            }
-        }
-        __syncthreads();
-        for (uint32_t i = tid; i < n; i += 256) point_list[r.x + scratch[r.x + i]] = (uint32_t)src[i];
-        return;
-    }
-    if (n == 2) {
-        if (tid == 0) {
-            const uint64_t a = src[0], bb = src[1];
-            point_list[r.x] = (uint32_t)(a < bb ? a : bb);
-            point_list[r.x + 1] = (uint32_t)(a < bb ? bb : a);
-        }
-        return;
-    }
-    // ---- bitonic network, m = next power of two >= n (>= 4), padded with +inf ----
-    // Each thread owns groups of 4 consecutive elements: the j = 2 and j = 1 steps of every level run in
-    // registers (one 32-byte LDS read + write per group instead of two passes).  Each wave owns whole
-    // 256-element blocks, so steps with j <= 128 need no workgroup barrier (LDS operations of one wave
-    // execute in order); only the cross-block steps (j >= 256: 1 for m = 512, 3 for m = 1024, ...) do.
-    for (uint32_t i = tid; i < m; i += 256) lds_keys[i] = i < n ? src[i] : ~0ull;
-    __syncthreads();
-    const uint32_t wave = tid >> 6, lane = tid & 63;
-    const uint32_t bsize = m < 256u ? m : 256u;            // elements per block
-    const uint32_t nblk = m / bsize;
-    auto cex = [](uint64_t &a, uint64_t &bb, bool asc) __attribute__((always_inline)) {
-        const bool sw = (a > bb) == asc;
-        const uint64_t lo = sw ? bb : a, hi = sw ? a : bb;
-        a = lo; bb = hi;
-    };
-    using u64x2 = uint64_t __attribute__((ext_vector_type(2)));
-    // phase 0: levels k = 2 and k = 4 == sort every 4-group, ascending iff bit 2 of its base index is 0
-    for (uint32_t b = wave; b < nblk; b += 4)
-        for (uint32_t q = lane; q < (bsize >> 2); q += 64) {
-            const uint32_t i0 = b * 256 + q * 4;
-            u64x2 *p = reinterpret_cast<u64x2 *>(lds_keys + i0);
-            u64x2 lo2 = p[0], hi2 = p[1];
-            uint64_t e0 = lo2.x, e1 = lo2.y, e2 = hi2.x, e3 = hi2.y;
-            const bool asc = (m == 4u) || ((i0 & 4u) == 0u);
-            cex(e0, e1, asc); cex(e2, e3, asc); cex(e0, e2, asc); cex(e1, e3, asc); cex(e1, e2, asc);
-            lo2.x = e0; lo2.y = e1; hi2.x = e2; hi2.y = e3;
-            p[0] = lo2; p[1] = hi2;
-        }
-    for (uint32_t k = 8; k <= m; k <<= 1) {
-        for (uint32_t j = k >> 1; j >= 4; j >>= 1) {
-            const uint32_t sh = 31u - (uint32_t)__builtin_clz(j);          // log2 j
-            if (j >= 256u) {                                               // cross-block step
-                __syncthreads();
-                for (uint32_t p = tid; p < (m >> 1); p += 256) {
-                    const uint32_t i = ((p >> sh) << (sh + 1)) + (p & (j - 1)), l = i + j;
-                    uint64_t a = lds_keys[i], bb = lds_keys[l];
-                    cex(a, bb, (i & k) == 0u);
-                    lds_keys[i] = a; lds_keys[l] = bb;
-                }
-                __syncthreads();
-            } else {                                                       // inside this wave's blocks
-                __builtin_amdgcn_wave_barrier();
-                for (uint32_t b = wave; b < nblk; b += 4)
-                    for (uint32_t lp = lane; lp < (bsize >> 1); lp += 64) {
-                        const uint32_t i = b * 256 + ((lp >> sh) << (sh + 1)) + (lp & (j - 1)), l = i + j;
-                        uint64_t a = lds_keys[i], bb = lds_keys[l];
-                        cex(a, bb, (i & k) == 0u);
-                        lds_keys[i] = a; lds_keys[l] = bb;
-                    }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t b = wave; b < nblk; b += 4)                          // j = 2 and j = 1 in registers
-            for (uint32_t q = lane; q < (bsize >> 2); q += 64) {
-                const uint32_t i0 = b * 256 + q * 4;
-                u64x2 *p = reinterpret_cast<u64x2 *>(lds_keys + i0);
-                u64x2 lo2 = p[0], hi2 = p[1];
-                uint64_t e0 = lo2.x, e1 = lo2.y, e2 = hi2.x, e3 = hi2.y;
-                const bool asc = (i0 & k) == 0u;
-                cex(e0, e2, asc); cex(e1, e3, asc); cex(e0, e1, asc); cex(e2, e3, asc);
-                lo2.x = e0; lo2.y = e1; hi2.x = e2; hi2.y = e3;
-                p[0] = lo2; p[1] = hi2;
-            }
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += 256) point_list[r.x + i] = (uint32_t)lds_keys[i];
-}
-
-hipError_t launch_tile_depth_sort(const BinningView &b, const ImageView &im, int T, hipStream_t s) {
-    if (T <= 0) return hipSuccess;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)tile_depth_sort_kernel<16384, 4096, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((tile_depth_sort_kernel<1024, 0, false>), dim3(T), dim3(256), 1024 * 8, s, im.ranges, b.dvals_sorted, b.point_list, (uint32_t *)b.dvals_unsorted);
-    hipLaunchKernelGGL((tile_depth_sort_kernel<4096, 1024, false>), dim3(T), dim3(256), 4096 * 8, s, im.ranges, b.dvals_sorted, b.point_list, (uint32_t *)b.dvals_unsorted);
-    hipLaunchKernelGGL((tile_depth_sort_kernel<16384, 4096, true>), dim3(T), dim3(256), 16384 * 8, s, im.ranges, b.dvals_sorted, b.point_list, (uint32_t *)b.dvals_unsorted);
-    return hipGetLastError();
-}
-
 __global__ __launch_bounds__(256) void emit_keys_kernel(int P, int W, int H, int gridx, int exact_cull, int two_level,
+                                                        const uint32_t *__restrict__ perm,
                                                         const uint32_t *__restrict__ tiles,
                                                         const uint32_t *__restrict__ offsets,
                                                         const uint2 *__restrict__ rect, const float *__restrict__ rec,
                                                         uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                        uint32_t *__restrict__ tkeys, uint64_t *__restrict__ dvals) {
+                                                        uint32_t *__restrict__ tkeys, uint32_t *__restrict__ ids) {
     const int lane = threadIdx.x & 63;
     const int g0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
     if (g0 >= P) return;                                  // wave-uniform
+    // the wave owns positions [g0, g0+64) of the depth-ordered Gaussian list; `offsets` is in that order
     const int g = g0 + lane;
-    const int gc = g < P ? g : P - 1;
     const uint32_t out_start = g0 > 0 ? offsets[g0 - 1] : 0u;   // first output slot of this wave
     const uint32_t out_total = offsets[min(g0 + 63, P - 1)] - out_start;
     if (out_total == 0) return;                           // wave-uniform
+    const int gc = (int)perm[g < P ? g : P - 1];          // Gaussian id of this lane
     const uint2 rc = rect[gc];
     const uint32_t rw = (rc.x >> 16) - (rc.x & 0xffffu), rh = (rc.y >> 16) - (rc.y & 0xffffu);
     // candidates = tiles of the 3-sigma rectangle; splats that emit nothing are not walked at all
@@ -253,15 +164,16 @@ __global__ __launch_bounds__(256) void emit_keys_kernel(int P, int W, int H, int
         }
         const uint64_t ballot = __ballot(pass);
         const uint32_t slot = running + (uint32_t)__popcll(ballot & lt_mask);
+        const uint32_t gid = __shfl((uint32_t)gc, src);      // all lanes active here
         if (pass && slot < out_total) {                   // slot < out_total always holds (same span function as the count)
             const uint32_t tile = (y0 + ty) * (uint32_t)gridx + (x0 + tx);
             const size_t o = (size_t)out_start + slot;
             if (two_level) {                              // wave-uniform
                 tkeys[o] = tile;
-                dvals[o] = ((uint64_t)db << 32) | (uint32_t)(g0 + src);
+                ids[o] = gid;
             } else {
                 keys[o] = ((uint64_t)tile << 32) | db;
-                vals[o] = (uint32_t)(g0 + src);
+                vals[o] = gid;
             }
         }
         running += (uint32_t)__popcll(ballot);
@@ -272,9 +184,10 @@ hipError_t launch_emit_keys(const GeomView &g, const BinningView &b, int P, int 
                             hipStream_t s) {
     if (P <= 0) return hipSuccess;
     const int gridx = (W + GSR_TILE - 1) / GSR_TILE;
+    // two-level: level 2 writes the sorted ids straight into point_list
     hipLaunchKernelGGL(emit_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, W, H, gridx, exact_cull, two_level,
-                       g.tiles, g.offsets, g.rect, g.rec, b.keys_unsorted, b.point_list_unsorted, b.tkeys_unsorted,
-                       b.dvals_unsorted);
+                       g.perm, g.tiles, g.offsets, g.rect, g.rec, b.keys_unsorted, b.point_list_unsorted, b.tkeys_unsorted,
+                       b.ids_unsorted);
     return hipGetLastError();
 }
 

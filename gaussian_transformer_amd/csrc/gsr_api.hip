@@ -23,7 +23,7 @@ static std::atomic<int> g_wpb{1};           // waves per workgroup of the compos
 static std::atomic<int> g_two_level_sort{1};   // 1: rocPRIM by tile + per-tile LDS depth sort; 0: one global 64-bit-key sort      // same for the forward compositing kernel      // 8x8 pixel blocks per wave in the reverse compositing kernel (1, 2 or 4)   // output-invariant exact splat-vs-tile culling (gsr_set_option)
 static float g_stage_ms[GSR_NUM_STAGES] = {0};
 static const char *const k_stage_names[GSR_NUM_STAGES] = {
-    "fwd.preprocess", "fwd.scan", "fwd.readback_N", "fwd.emit_keys", "fwd.sort", "fwd.ranges", "fwd.tile_depth_sort",
+    "fwd.preprocess", "fwd.depth_order+scan", "fwd.readback_N", "fwd.emit_keys", "fwd.sort", "fwd.ranges", "(unused)",
     "fwd.composite", "bwd.zero_acc", "bwd.composite", "bwd.pergauss", "fwd.total", "bwd.total"};
 
 static int fail(int code, const char *fmt, ...) {
@@ -39,7 +39,7 @@ static int fail(int code, const char *fmt, ...) {
         if (_e != hipSuccess) return fail(GSR_ERR_HIP, "%s: %s (%d)", what, hipGetErrorString(_e), (int)_e); \
     } while (0)
 
-GeomView carve_geom(void *base, int P, size_t scan_tb) {
+GeomView carve_geom(void *base, int P, size_t scan_tb, size_t dsort_tb) {
     GeomView g;
     const size_t n = (size_t)(P > 0 ? P : 1);
     char *p = (char *)base;
@@ -51,8 +51,12 @@ GeomView carve_geom(void *base, int P, size_t scan_tb) {
     g.tiles = (uint32_t *)take(n * sizeof(uint32_t));
     g.offsets = (uint32_t *)take(n * sizeof(uint32_t));
     g.clamped = (uint8_t *)take(n);
+    g.perm = (uint32_t *)take(n * sizeof(uint32_t));
+    g.depth_sorted = (uint32_t *)take(n * sizeof(uint32_t));
     g.scan_temp = take(scan_tb);
     g.scan_temp_bytes = scan_tb;
+    g.dsort_temp = take(dsort_tb);
+    g.dsort_temp_bytes = dsort_tb;
     g.total_bytes = off;
     return g;
 }
@@ -81,7 +85,7 @@ BinningView carve_binning(void *base, int64_t N, size_t sort_tb) {
     b.keys_sorted = (uint64_t *)take(n * sizeof(uint64_t));
     b.keys_unsorted = (uint64_t *)take(n * sizeof(uint64_t));
     b.point_list_unsorted = (uint32_t *)take(n * sizeof(uint32_t));
-    b.tkeys_unsorted = b.point_list; b.dvals_sorted = b.keys_sorted; b.dvals_unsorted = b.keys_unsorted;
+    b.tkeys_unsorted = (uint32_t *)b.keys_sorted; b.ids_sorted = b.point_list; b.ids_unsorted = (uint32_t *)b.keys_unsorted;
     b.tkeys_sorted = b.point_list_unsorted;
     b.sort_temp = take(sort_tb);
     b.sort_temp_bytes = sort_tb;
@@ -179,9 +183,10 @@ int32_t gsr_get_stage_times(const char **names, float *ms) {
 int32_t gsr_workspace_sizes(int32_t P, int32_t W, int32_t H, size_t *geom_bytes, size_t *img_bytes, size_t *bwd_bytes) {
     if (P < 0 || W <= 0 || H <= 0) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_workspace_sizes: P=%d W=%d H=%d", P, W, H);
     if (W > 65535 * GSR_TILE_HOST || H > 65535 * GSR_TILE_HOST) return fail(GSR_ERR_INVALID_ARGUMENT, "image too large");
-    size_t stb = 0;
+    size_t stb = 0, dtb = 0;
     HIP_TRY(scan_temp_bytes(P, &stb), "scan temp query");
-    if (geom_bytes) *geom_bytes = carve_geom(nullptr, P, stb).total_bytes;
+    HIP_TRY(depth_sort_temp_bytes(P, &dtb), "depth sort temp query");
+    if (geom_bytes) *geom_bytes = carve_geom(nullptr, P, stb, dtb).total_bytes;
     if (img_bytes) *img_bytes = carve_image(nullptr, W, H).total_bytes;
     if (bwd_bytes) *bwd_bytes = align_up((size_t)(P > 0 ? P : 1) * GSR_ACC_FLOATS * sizeof(float));
     return GSR_OK;
@@ -224,9 +229,10 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
         if (M < (D + 1) * (D + 1)) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward: M=%d < (D+1)^2=%d", M, (D + 1) * (D + 1));
         if (!campos) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward: campos required with shs");
     }
-    size_t stb = 0;
+    size_t stb = 0, dtb = 0;
     HIP_TRY(scan_temp_bytes(P, &stb), "scan temp query");
-    GeomView g = carve_geom(geom_ws, P, stb);
+    HIP_TRY(depth_sort_temp_bytes(P, &dtb), "depth sort temp query");
+    GeomView g = carve_geom(geom_ws, P, stb, dtb);
     ImageView im = carve_image(img_ws, W, H);
     if (geom_bytes < g.total_bytes) return fail(GSR_ERR_WORKSPACE, "geom workspace %zu < %zu", geom_bytes, g.total_bytes);
     if (img_bytes < im.total_bytes) return fail(GSR_ERR_WORKSPACE, "image workspace %zu < %zu", img_bytes, im.total_bytes);
@@ -243,8 +249,9 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     HIP_TRY(launch_preprocess_fwd(pa, s), "preprocess launch");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "preprocess");
     tm.mark(1);
-    HIP_TRY(launch_scan(g, P, s), "scan");
-    if (debug) HIP_TRY(hipStreamSynchronize(s), "scan");
+    HIP_TRY(launch_depth_sort(g, P, s), "depth sort");
+    HIP_TRY(launch_ordered_scan(g, P, s), "ordered scan");
+    if (debug) HIP_TRY(hipStreamSynchronize(s), "depth order + scan");
     tm.mark(2);
     uint32_t n32 = 0;
     HIP_TRY(hipMemcpyAsync(&n32, g.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read N");
@@ -272,11 +279,6 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     tm.mark(5);
     HIP_TRY(launch_ranges(b, im, N, T, two_level, s), "tile ranges");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "tile ranges");
-    tm.mark(6);
-    if (two_level && N > 0) {
-        HIP_TRY(launch_tile_depth_sort(b, im, T, s), "per-tile depth sort");
-        if (debug) HIP_TRY(hipStreamSynchronize(s), "per-tile depth sort");
-    }
     tm.mark(7);
     CompositeArgs ca;
     ca.W = W; ca.H = H; ca.gridx = gridx; ca.gridy = gridy; ca.ranges = im.ranges; ca.point_list = b.point_list;
@@ -310,9 +312,10 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
         return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: SH inputs inconsistent");
     if (scales && (!dL_dscales || !dL_drots)) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: dL_dscales/dL_drots required");
     if (R > 0 && !binning_ws) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: binning workspace missing");
-    size_t stb = 0;
+    size_t stb = 0, dtb = 0;
     HIP_TRY(scan_temp_bytes(P, &stb), "scan temp query");
-    GeomView g = carve_geom(const_cast<void *>(geom_ws), P, stb);
+    HIP_TRY(depth_sort_temp_bytes(P, &dtb), "depth sort temp query");
+    GeomView g = carve_geom(const_cast<void *>(geom_ws), P, stb, dtb);
     ImageView im = carve_image(const_cast<void *>(img_ws), W, H);
     if (geom_bytes < g.total_bytes) return fail(GSR_ERR_WORKSPACE, "geom workspace %zu < %zu", geom_bytes, g.total_bytes);
     if (img_bytes < im.total_bytes) return fail(GSR_ERR_WORKSPACE, "image workspace %zu < %zu", img_bytes, im.total_bytes);
@@ -362,9 +365,10 @@ int32_t gsr_debug_read_geom(gsr_stream_t stream, int32_t P, const void *geom_ws,
                             float *conic_opacity, float *rgb, uint32_t *tiles_touched, uint8_t *clamped) {
     hipStream_t s = (hipStream_t)stream;
     if (P <= 0) return GSR_OK;
-    size_t stb = 0;
+    size_t stb = 0, dtb = 0;
     HIP_TRY(scan_temp_bytes(P, &stb), "scan temp query");
-    GeomView g = carve_geom(const_cast<void *>(geom_ws), P, stb);
+    HIP_TRY(depth_sort_temp_bytes(P, &dtb), "depth sort temp query");
+    GeomView g = carve_geom(const_cast<void *>(geom_ws), P, stb, dtb);
     HIP_TRY(hipStreamSynchronize(s), "sync");
     float *rec = (float *)malloc((size_t)P * GSR_REC_FLOATS * sizeof(float));
     uint8_t *cl = (uint8_t *)malloc((size_t)P);
@@ -391,7 +395,7 @@ int32_t gsr_debug_read_binning(gsr_stream_t stream, int64_t N, int32_t W, int32_
     HIP_TRY(hipStreamSynchronize(s), "sync");
     if (N > 0 && binning_ws) {
         BinningView b = carve_binning(const_cast<void *>(binning_ws), N, 0);
-        // global-sort mode: tile<<32|depth ; two-level mode: depth<<32|id grouped by tile
+        // global-sort mode: tile<<32|depth ; meaningless in two-level mode
         if (keys_sorted) HIP_TRY(hipMemcpy(keys_sorted, b.keys_sorted, (size_t)N * 8, hipMemcpyDeviceToHost), "copy keys");
         if (point_list) HIP_TRY(hipMemcpy(point_list, b.point_list, (size_t)N * 4, hipMemcpyDeviceToHost), "copy point list");
     }

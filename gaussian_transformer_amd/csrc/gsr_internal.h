@@ -25,13 +25,17 @@ struct GeomView {          // per-Gaussian state, P entries each
     float *depth;          // [P]
     uint2 *rect;           // [P] (x0 | x1<<16, y0 | y1<<16)
     uint32_t *tiles;       // [P] (Gaussian,tile) pairs emitted (== rect area when exact culling is off)
-    uint32_t *offsets;     // [P] inclusive scan of tiles
+    uint32_t *offsets;     // [P] inclusive scan of tiles[perm[.]] (depth order)
     uint8_t *clamped;      // [P] bit ch set iff SH colour channel ch was clamped at 0
+    uint32_t *perm;        // [P] Gaussian ids in (depth, id) order
+    uint32_t *depth_sorted;  // [P] sorted depth bits (by-product of the depth sort)
     void *scan_temp;
     size_t scan_temp_bytes;
+    void *dsort_temp;
+    size_t dsort_temp_bytes;
     size_t total_bytes;
 };
-GeomView carve_geom(void *base, int P, size_t scan_temp_bytes);
+GeomView carve_geom(void *base, int P, size_t scan_temp_bytes, size_t dsort_temp_bytes);
 
 struct ImageView {
     uint2 *ranges;         // [T]
@@ -44,15 +48,15 @@ ImageView carve_image(void *base, int W, int H);
 struct BinningView {
     // one 24-byte-per-pair arena, two interpretations (regions A 4N | B 8N | C 8N | D 4N):
     //   global sort  : A point_list (sorted ids) | B keys_sorted u64 | C keys_unsorted u64 | D ids_unsorted
-    //   two-level    : A tile keys unsorted, then point_list (the tile keys are dead once rocPRIM has
-    //                  read them) | B (depth<<32|id) sorted by tile | C same, unsorted | D tile keys sorted
+    //   two-level    : A point_list (ids sorted by tile, in depth order) | B tile keys unsorted (u32)
+    //                  | C ids unsorted (u32) | D tile keys sorted
     uint32_t *point_list;        // [N] sorted Gaussian ids           (read by backward)
     uint64_t *keys_sorted;       // [N]
     uint64_t *keys_unsorted;     // [N]
     uint32_t *point_list_unsorted;  // [N]
     uint32_t *tkeys_unsorted;    // = A
-    uint64_t *dvals_sorted;      // = B
-    uint64_t *dvals_unsorted;    // = C
+    uint32_t *ids_sorted;        // = B
+    uint32_t *ids_unsorted;      // = C
     uint32_t *tkeys_sorted;      // = D
     void *sort_temp;
     size_t sort_temp_bytes;
@@ -78,7 +82,9 @@ hipError_t sort_temp_bytes(int64_t N, int bits, size_t *bytes);
 hipError_t launch_emit_keys(const GeomView &g, const BinningView &b, int P, int W, int H, int exact_cull, int two_level, hipStream_t s);
 hipError_t sort2_temp_bytes(int64_t N, int tile_bits, size_t *bytes);
 hipError_t launch_sort2_by_tile(const BinningView &b, int64_t N, int tile_bits, hipStream_t s);
-hipError_t launch_tile_depth_sort(const BinningView &b, const ImageView &im, int T, hipStream_t s);
+hipError_t depth_sort_temp_bytes(int P, size_t *bytes);
+hipError_t launch_depth_sort(const GeomView &g, int P, hipStream_t s);
+hipError_t launch_ordered_scan(const GeomView &g, int P, hipStream_t s);
 hipError_t launch_sort(const BinningView &b, int64_t N, int bits, hipStream_t s);
 hipError_t launch_ranges(const BinningView &b, const ImageView &im, int64_t N, int T, int two_level, hipStream_t s);
 

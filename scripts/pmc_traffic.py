@@ -9,8 +9,7 @@ import csv, glob, json, os, sys, collections
 d, tag, out = sys.argv[1], sys.argv[2], sys.argv[3]
 STAGES = [("composite_bwd_kernel", "bwd.composite"), ("composite_fwd_kernel", "fwd.composite"),
           ("preprocess_fwd_kernel", "fwd.preprocess"), ("pergauss_bwd_kernel", "bwd.pergauss"),
-          ("emit_keys_kernel", "fwd.emit_keys"), ("tile_ranges", "fwd.ranges"), ("tile_depth_sort_kernel", "fwd.tile_depth_sort"),
-          ("scan", "fwd.scan"), ("onesweep", "fwd.sort"), ("histogram", "fwd.sort"), ("radix_sort", "fwd.sort"), ("rocprim", "fwd.sort")]
+          ("emit_keys_kernel", "fwd.emit_keys"), ("tile_ranges", "fwd.ranges"), ("scan", "fwd.depth_order+scan"), ("onesweep", "fwd.sort"), ("histogram", "fwd.sort"), ("radix_sort", "fwd.sort"), ("rocprim", "fwd.sort")]
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 steps = 0
 for f in sorted(glob.glob(os.path.join(d, f"{tag}_pass*_counter_collection.csv"))):
