@@ -96,8 +96,16 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
         Tr[q] = Tf; acc0[q] = acc1[q] = acc2[q] = 0.f;
         max_last = max(max_last, last[q]);
     }
+    int blk_last[NPX];                                // last contributor over the 64 pixels of block q (wave-uniform)
 #pragma unroll
-    for (int m = 32; m > 0; m >>= 1) max_last = max(max_last, __shfl_xor(max_last, m));
+    for (int q = 0; q < NPX; q++) {
+        int m = last[q];
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) m = max(m, __shfl_xor(m, sft));
+        blk_last[q] = __builtin_amdgcn_readfirstlane(m);
+        max_last = max(max_last, blk_last[q]);
+    }
+    max_last = __builtin_amdgcn_readfirstlane(max_last);
     if (max_last == 0) return;                        // wave-uniform
 
     // Cross-lane reduction through LDS (the LDS pipe is idle otherwise, the VALU is the bottleneck):
@@ -168,13 +176,17 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
                 v5 += sx * dx; v6 += sx * dy; v7 += sy * dy;
             };
 #ifndef GSR_ABL_NOMATH
-            if (bits == (1u << NPX) - 1u) {           // scalar branch: every block reachable -> one basic block
+            uint32_t todo_bits = bits;                // drop blocks whose pixels all stopped before this splat
+#pragma unroll
+            for (int q = 0; q < NPX; q++)
+                if (pos >= blk_last[q]) todo_bits &= ~(1u << q);
+            if (todo_bits == (1u << NPX) - 1u) {      // scalar branch: every block needed -> one basic block
 #pragma unroll
                 for (int q = 0; q < NPX; q++) block_body(q);
             } else {
 #pragma unroll
                 for (int q = 0; q < NPX; q++)
-                    if (bits & (1u << q)) block_body(q);
+                    if (todo_bits & (1u << q)) block_body(q);
             }
 #else
             v0 = r0.x * fx[0]; v8 = r1.y;

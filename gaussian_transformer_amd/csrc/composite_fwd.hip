@@ -59,6 +59,10 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
         all_done = all_done && done[q];
     }
 
+    uint32_t blk_done = 0;                            // bit q: every pixel of block q is saturated (wave-uniform)
+#pragma unroll
+    for (int q = 0; q < NPX; q++)
+        if (__all(done[q])) blk_done |= 1u << q;
     for (int base = 0; base < n; base += 64) {
         if (__all(all_done)) break;                   // wave-uniform
         const int cnt = min(64, n - base);
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
             bool any_stop = false;
 #pragma unroll
             for (int q = 0; q < NPX; q++) {
-                if (!(bits & (1u << q))) continue;    // scalar branch
+                if (!(bits & ~blk_done & (1u << q))) continue;    // scalar branch: unreachable or saturated block
                 const float dx = r0.x - fx[q], dy = r0.y - fy[q];
                 const float power = (r0.z * dx + r0.w * dy) * dx + (r1.x * dy) * dy;   // log2 units
                 const float alpha = fminf(GSR_ALPHA_MAX, r1.y * __builtin_amdgcn_exp2f(power));
@@ -111,7 +115,10 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
             if (__any(any_stop)) {                    // wave-uniform
                 all_done = true;
 #pragma unroll
-                for (int q = 0; q < NPX; q++) all_done = all_done && done[q];
+                for (int q = 0; q < NPX; q++) {
+                    all_done = all_done && done[q];
+                    if (__all(done[q])) blk_done |= 1u << q;
+                }
                 if (__all(all_done)) { todo = 0; }
             }
         }
