@@ -68,11 +68,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)        # one rank per GPU; wraps only in single-GPU rehearsals
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("GSR_DIST_BACKEND", "nccl")     # "nccl" = RCCL over xGMI; "gloo" for rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     for kv in args.opt:
         k, v = kv.split("=")
@@ -99,19 +105,22 @@ def main():
         image_height=H, image_width=W, tanfovx=cam_np.tanfovx, tanfovy=cam_np.tanfovy, bg=bg, scale_modifier=1.0,
         viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=D,
         campos=cam.camera_center, prefiltered=False, debug=False)
-    flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev) if world > 1 else None
+    from gaussian_transformer_amd.rasterizer import arena_floats, gradient_arena
+    # N > 1: the backward pass writes the 59 floats/Gaussian of parameter gradients straight into one flat
+    # bucket, which is summed over the ranks with ONE all-reduce (RCCL over xGMI) inside the step.
+    flat = torch.zeros(arena_floats(P, M), dtype=torch.float32, device=dev) if world > 1 else None
     state = {}
 
     def step():
         means2D = torch.zeros((P, 3), dtype=torch.float32, device=dev, requires_grad=True)
         rast = GaussianRasterizer(raster_settings=rs)
         color, radii = rast(means3D=means3D, means2D=means2D, shs=shs, opacities=opac, scales=scales, rotations=rots)
-        grads = torch.autograd.grad(color, params, grad_outputs=dL)
         if world > 1:
-            off = 0
-            for g in grads:
-                flat[off:off + g.numel()].copy_(g.reshape(-1)); off += g.numel()
+            with gradient_arena(flat):
+                grads = torch.autograd.grad(color, params, grad_outputs=dL)
             dist.all_reduce(flat)
+        else:
+            grads = torch.autograd.grad(color, params, grad_outputs=dL)
         state["color"], state["grads"] = color, grads
 
     def sync():
@@ -216,6 +225,7 @@ def main():
             "value": round(value, 3), "unit": "renders/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "allreduce_bytes_per_step": (flat.numel() * 4 if flat is not None else 0),
             "config": {"workload": args.config, "gaussians": P, "width": W, "height": H, "sh_degree": D,
                        "num_rendered_pairs": int(N), "pairs_under_reference_tile_rule": int(N_ref_rule),
                        "cameras_per_step": world,

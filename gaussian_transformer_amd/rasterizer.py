@@ -113,13 +113,30 @@ class HipBackend:
             stream = torch.cuda.current_stream(dev).cuda_stream
             _, _, bb = self._sizes(P, W, H)
             bwd_ws = torch.empty((bb,), dtype=torch.uint8, device=dev)
-            g_means2D = torch.empty((P, 3), **f32); g_opacity = torch.empty((P, 1), **f32)
-            g_colors = torch.empty((P, 3), **f32); g_means3D = torch.empty((P, 3), **f32)
-            g_cov3D = torch.empty((P, 6), **f32)
-            g_sh = torch.empty((P, M, 3), **f32) if M > 0 else torch.empty((0,), **f32)
             has_sr = scales.numel() > 0
-            g_scales = torch.empty((P, 3), **f32) if has_sr else torch.empty((0,), **f32)
-            g_rots = torch.empty((P, 4), **f32) if has_sr else torch.empty((0,), **f32)
+            arena = _grad_arena
+            if arena is not None and (arena.device != dev or arena.dtype != torch.float32 or not arena.is_contiguous()
+                                      or arena.numel() < arena_floats(P, M, has_sr)):
+                raise _lib.GsrError("gradient arena must be a contiguous float32 tensor on the render device with "
+                                    f"at least {arena_floats(P, M, has_sr)} elements")
+            off = [0]
+
+            def out(shape):
+                n = 1
+                for d in shape:
+                    n *= d
+                if arena is None or n == 0:
+                    return torch.empty(shape, **f32)
+                v = arena[off[0]:off[0] + n].view(shape)
+                off[0] += n
+                return v
+            g_means3D = out((P, 3))
+            g_sh = out((P, M, 3)) if M > 0 else torch.empty((0,), **f32)
+            g_opacity = out((P, 1))
+            g_scales = out((P, 3)) if has_sr else torch.empty((0,), **f32)
+            g_rots = out((P, 4)) if has_sr else torch.empty((0,), **f32)
+            g_means2D = torch.empty((P, 3), **f32); g_colors = torch.empty((P, 3), **f32)
+            g_cov3D = torch.empty((P, 6), **f32)
             bg = _f32c(rs.bg, "bg", dev); vm = _f32c(rs.viewmatrix, "viewmatrix", dev)
             pm = _f32c(rs.projmatrix, "projmatrix", dev); cp = _f32c(rs.campos, "campos", dev)
             dL = _f32c(dL_dpix, "grad of rendered image", dev)
@@ -148,6 +165,31 @@ class HipBackend:
 
 
 _backend = None
+_grad_arena = None      # optional flat float32 tensor the backward pass carves its parameter gradients from
+
+
+class gradient_arena:
+    """Context manager: while active, gsr_backward writes dL/d{means3D, shs, opacities, scales, rotations}
+    straight into consecutive slices of `flat` (59 floats per Gaussian at M = 16, in that order), so a
+    data-parallel step can all-reduce `flat` without a packing copy.  The returned gradient tensors are
+    views of `flat`."""
+
+    def __init__(self, flat: torch.Tensor):
+        self.flat = flat
+
+    def __enter__(self):
+        global _grad_arena
+        self.prev, _grad_arena = _grad_arena, self.flat
+        return self.flat
+
+    def __exit__(self, *exc):
+        global _grad_arena
+        _grad_arena = self.prev
+        return False
+
+
+def arena_floats(P: int, M: int, has_scale_rot: bool = True) -> int:
+    return P * (3 + 3 * M + 1 + (7 if has_scale_rot else 0))
 
 
 def get_backend():

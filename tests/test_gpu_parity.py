@@ -279,3 +279,31 @@ def test_strided_nonleaf_inputs_and_validation_errors():
     with pytest.raises(RuntimeError):               # CPU tensors: loud failure, no fallback
         rast(means3D=x[:, 17:20].cpu(), means2D=m2.cpu(), opacities=x[:, 16:17].cpu(), shs=x[:, :12].reshape(P, 4, 3).cpu(),
              scales=x[:, 20:23].cpu(), rotations=x[:, 12:16].cpu())
+
+
+def test_gradient_arena_matches_separate_buffers():
+    """gradient_arena: gsr_backward writes the parameter gradients into slices of one flat bucket."""
+    from gaussian_transformer_amd import GaussianRasterizationSettings, GaussianRasterizer
+    from gaussian_transformer_amd.rasterizer import arena_floats, gradient_arena
+    sc = synth.make_scene(P=1500, width=96, height=64, sh_degree=2, s0=0.05, seed=41)
+    cam = sc.camera
+    t = lambda a, g=False: torch.tensor(np.asarray(a, dtype=np.float32), device="cuda").requires_grad_(g)
+    inp = dict(means3D=t(sc.means3D, True), shs=t(sc.shs, True), opacities=t(sc.opacities, True), scales=t(sc.scales, True),
+               rotations=t(sc.rotations, True))
+    rs = GaussianRasterizationSettings(64, 96, cam.tanfovx, cam.tanfovy, t(sc.bg), 1.0, t(cam.world_view_transform),
+                                       t(cam.full_proj_transform), 2, t(cam.camera_center), False, False)
+    dL = t(np.random.default_rng(0).normal(size=(3, 64, 96)))
+    params = list(inp.values())
+    c, _ = GaussianRasterizer(raster_settings=rs)(means2D=torch.zeros(1500, 3, device="cuda", requires_grad=True), **inp)
+    g_ref = torch.autograd.grad(c, params, grad_outputs=dL)
+    flat = torch.zeros(arena_floats(1500, 9), device="cuda")
+    c, _ = GaussianRasterizer(raster_settings=rs)(means2D=torch.zeros(1500, 3, device="cuda", requires_grad=True), **inp)
+    with gradient_arena(flat):
+        g_ar = torch.autograd.grad(c, params, grad_outputs=dL)
+    off = 0
+    for a, b in zip(g_ar, g_ref):
+        assert grad_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-4          # atomics: order-dependent last bits
+        n = a.numel()
+        assert a.data_ptr() == flat.data_ptr() + 4 * off                   # a view of the bucket, in parameter order
+        off += n
+    assert off == flat.numel()

@@ -112,3 +112,22 @@ def test_render_wrapper_dict_and_means2d_gradient(oracle_backend):
     with torch.no_grad():
         img3 = render(cam, pc, PipelineParams(), torch.tensor(sc.bg), scaling_modifier=0.5)["render"]
     assert not img3.requires_grad and float((img3 - img0).abs().max()) > 1e-3
+
+
+def test_gradient_arena_views(oracle_backend):
+    """Backward can write the parameter gradients straight into one flat bucket (no packing copy)."""
+    from gaussian_transformer_amd.rasterizer import arena_floats, gradient_arena
+    sc = synth.make_scene(P=50, width=32, height=32, sh_degree=1, s0=0.1, max_sh_degree=1)
+    t = lambda a: torch.tensor(a).requires_grad_(True)
+    inp = dict(means3D=t(sc.means3D), shs=t(sc.shs), opacities=t(sc.opacities), scales=t(sc.scales), rotations=t(sc.rotations))
+    rast = GaussianRasterizer(raster_settings=_settings(sc.camera, sc.bg, 1))
+    dL = torch.tensor(sc.dL_dimage)
+    c, _ = rast(means2D=torch.zeros(50, 3, requires_grad=True), **inp)
+    ref_g = torch.autograd.grad(c, list(inp.values()), grad_outputs=dL)
+    # the stand-in backend does not use the arena itself; check the carving helper and size rule
+    assert arena_floats(50, 4) == 50 * (3 + 12 + 1 + 3 + 4)
+    flat = torch.zeros(arena_floats(50, 4))
+    with gradient_arena(flat) as f:
+        assert f is flat and rasterizer._grad_arena is flat
+    assert rasterizer._grad_arena is None
+    assert all(torch.isfinite(g).all() for g in ref_g)
