@@ -1,10 +1,8 @@
 // binning.hip -- scan of tiles-touched, (tile, depth) key emission (S7), global radix sort,
 // per-tile range detection (S8).  All HBM-streaming stages.
 //
-// Key emission is work-balanced: a wave owns 64 consecutive Gaussians and its lanes walk the
-// wave's flattened output range (one output pair per lane per step, found by a 6-step search
-// over the wave's 64 scan values with ds_bpermute), so a splat covering a thousand tiles costs
-// the same per pair as one covering four, and every store is a contiguous 64-lane row.
+// Key emission is work-balanced in two levels (rows of the splat rectangles, then output pairs), each a
+// flattened walk with a 6-step ds_bpermute search over a wave-wide scan -- see emit_keys_kernel.
 #include <cstring>  // ROCm 7.2 rocprim/texture_cache_iterator.hpp uses memset without including it
 #include <rocprim/rocprim.hpp>
 
@@ -100,6 +98,31 @@ hipError_t launch_sort2_by_tile(const BinningView &b, int64_t N, int tile_bits, 
                                      (unsigned)tile_bits, s, false);
 }
 
+// wave-wide inclusive scan (all 64 lanes active)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+// number of lanes whose inclusive-scan value is <= j  (== index of the lane that owns slot j)
+__device__ __forceinline__ int owner_lane(uint32_t incl, uint32_t j) {
+    int lo = 0;
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) {
+        const uint32_t v = __shfl(incl, (lo + step - 1) & 63);
+        if (v <= j) lo += step;
+    }
+    return lo;
+}
+
+// Key emission, two balanced levels.  A wave owns 64 consecutive Gaussians of the depth-ordered list.
+// Level 1 walks the wave's flattened list of (Gaussian, tile ROW) items, one item per lane per step: the
+// ellipse-vs-row span (two sqrt) is evaluated once per row, not once per candidate tile.  Level 2 walks
+// the flattened list of the step's output pairs, one pair per lane: a splat covering a thousand tiles
+// costs the same per pair as one covering four, and every store is a contiguous 64-lane row.
 __global__ __launch_bounds__(256) void emit_keys_kernel(int P, int W, int H, int gridx, int exact_cull, int two_level,
                                                         const uint32_t *__restrict__ perm,
                                                         const uint32_t *__restrict__ tiles,
@@ -117,66 +140,60 @@ __global__ __launch_bounds__(256) void emit_keys_kernel(int P, int W, int H, int
     if (out_total == 0) return;                           // wave-uniform
     const int gc = (int)perm[g < P ? g : P - 1];          // Gaussian id of this lane
     const uint2 rc = rect[gc];
-    const uint32_t rw = (rc.x >> 16) - (rc.x & 0xffffu), rh = (rc.y >> 16) - (rc.y & 0xffffu);
-    // candidates = tiles of the 3-sigma rectangle; splats that emit nothing are not walked at all
-    const uint32_t cand = (g < P && tiles[gc] > 0u) ? rw * rh : 0u;
-    uint32_t incl = cand;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t v = __shfl_up(incl, d);
-        if (lane >= d) incl += v;
-    }
-    const uint32_t excl = incl - cand;
-    const uint32_t total = __shfl(incl, 63);
+    const uint32_t rh = (rc.y >> 16) - (rc.y & 0xffffu);
+    // level-1 items = tile rows of the 3-sigma rectangle; splats that emit nothing are not walked at all
+    const uint32_t nrows = (g < P && tiles[gc] > 0u) ? rh : 0u;
+    const uint32_t rincl = wave_inclusive_scan(nrows, lane);
+    const uint32_t rexcl = rincl - nrows;
+    const uint32_t rtotal = __shfl(rincl, 63);
     const float4 r0 = reinterpret_cast<const float4 *>(rec)[3 * (size_t)gc];
     const float4 r1 = reinterpret_cast<const float4 *>(rec)[3 * (size_t)gc + 1];
     const float4 r2 = reinterpret_cast<const float4 *>(rec)[3 * (size_t)gc + 2];
     const uint32_t dbits = __float_as_uint(r2.y);
     const CullParams cp = make_cull(r0.z, r0.w, r1.x, r2.z);
     uint32_t running = 0;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-    // wave-uniform trip count: every lane stays active for the cross-lane reads
-    for (uint32_t base = 0; base < total; base += 64) {
-        const uint32_t j = base + lane;
-        int lo = 0;                                       // number of lanes whose incl <= j
-#pragma unroll
-        for (int step = 32; step > 0; step >>= 1) {
-            const uint32_t v = __shfl(incl, (lo + step - 1) & 63);
-            if (v <= j) lo += step;
-        }
-        const int src = lo & 63;                          // lo == 64 only for j >= total (not stored)
-        const uint32_t e = __shfl(excl, src);
+    for (uint32_t rbase = 0; rbase < rtotal; rbase += 64) {      // wave-uniform trip count
+        // ---- level 1: one (Gaussian, row) item per lane ----
+        const uint32_t j = rbase + lane;
+        const int src = owner_lane(rincl, j) & 63;               // == 64 only for j >= rtotal (masked below)
         const uint32_t rx = __shfl(rc.x, src), ry = __shfl(rc.y, src);
-        const uint32_t db = __shfl(dbits, src);
         const uint32_t x0 = rx & 0xffffu, x1 = rx >> 16, y0 = ry & 0xffffu;
-        const uint32_t w = max(x1 - x0, 1u);
-        const uint32_t k = j - e;
-        const uint32_t ty = k / w, tx = k - ty * w;
-        bool pass = j < total;
-        if (exact_cull) {                                 // wave-uniform
+        const uint32_t row = y0 + (j - __shfl(rexcl, src));
+        const uint32_t gid = __shfl((uint32_t)gc, src);
+        const uint32_t db = __shfl(dbits, src);
+        int c0 = (int)x0, c1 = (int)x1;
+        if (exact_cull) {                                        // wave-uniform
             CullParams c;
             c.tau = __shfl(cp.tau, src); c.xmax = __shfl(cp.xmax, src); c.ymax = __shfl(cp.ymax, src);
             c.dy_at_xmax = __shfl(cp.dy_at_xmax, src); c.det = __shfl(cp.det, src);
             const float px = __shfl(r0.x, src), py = __shfl(r0.y, src), A = __shfl(r0.z, src), B = __shfl(r0.w, src);
-            int c0, c1;
-            tile_row_span(c, px, py, A, B, (int)(y0 + ty), W, H, (int)x0, (int)x1, c0, c1);
-            pass = pass && ((int)(x0 + tx) >= c0) && ((int)(x0 + tx) < c1);
+            tile_row_span(c, px, py, A, B, (int)row, W, H, (int)x0, (int)x1, c0, c1);
         }
-        const uint64_t ballot = __ballot(pass);
-        const uint32_t slot = running + (uint32_t)__popcll(ballot & lt_mask);
-        const uint32_t gid = __shfl((uint32_t)gc, src);      // all lanes active here
-        if (pass && slot < out_total) {                   // slot < out_total always holds (same span function as the count)
-            const uint32_t tile = (y0 + ty) * (uint32_t)gridx + (x0 + tx);
-            const size_t o = (size_t)out_start + slot;
-            if (two_level) {                              // wave-uniform
-                tkeys[o] = tile;
-                ids[o] = gid;
-            } else {
-                keys[o] = ((uint64_t)tile << 32) | db;
-                vals[o] = gid;
+        const uint32_t cnt = j < rtotal ? (uint32_t)(c1 - c0) : 0u;
+        const uint32_t cincl = wave_inclusive_scan(cnt, lane);
+        const uint32_t cexcl = cincl - cnt;
+        const uint32_t ctotal = __shfl(cincl, 63);
+        const uint32_t tile0 = row * (uint32_t)gridx + (uint32_t)c0;      // first tile of this item's span
+        // ---- level 2: one output pair per lane ----
+        for (uint32_t obase = 0; obase < ctotal; obase += 64) {           // wave-uniform trip count
+            const uint32_t t = obase + lane;
+            const int it = owner_lane(cincl, t) & 63;
+            const uint32_t tile = __shfl(tile0, it) + (t - __shfl(cexcl, it));
+            const uint32_t id = __shfl(gid, it);
+            const uint32_t d = __shfl(db, it);
+            const uint32_t slot = running + t;
+            if (t < ctotal && slot < out_total) {                 // slot < out_total always holds (same span function as the count)
+                const size_t o = (size_t)out_start + slot;
+                if (two_level) {                                  // wave-uniform
+                    tkeys[o] = tile;
+                    ids[o] = id;
+                } else {
+                    keys[o] = ((uint64_t)tile << 32) | d;
+                    vals[o] = id;
+                }
             }
         }
-        running += (uint32_t)__popcll(ballot);
+        running += ctotal;
     }
 }
 
