@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "../../include/gsr.h"
+#include "../../include/gsr_loss.h"
 #include "gsr_internal.h"
 
 namespace gsr {
@@ -350,6 +351,38 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     if (debug) HIP_TRY(hipStreamSynchronize(s), "per-Gaussian backward");
     tm.mark(-1);
     tm.finish(12);
+    return GSR_OK;
+}
+
+// ---- fused training loss (include/gsr_loss.h) ----
+static inline size_t loss_blocks(int C, int H, int W) { return (size_t)((W + 15) / 16) * ((H + 15) / 16) * C; }
+
+int32_t gsr_l1_ssim_workspace(int32_t C, int32_t H, int32_t W, size_t *bytes) {
+    if (C <= 0 || H <= 0 || W <= 0 || !bytes) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_l1_ssim_workspace: bad argument");
+    *bytes = align_up((size_t)3 * C * H * W * sizeof(float)) + align_up(loss_blocks(C, H, W) * 2 * sizeof(float));
+    return GSR_OK;
+}
+
+int32_t gsr_l1_ssim_forward(gsr_stream_t stream, int32_t C, int32_t H, int32_t W, const float *img, const float *gt,
+                            float lambda_dssim, float *out3, void *ws, size_t ws_bytes) {
+    size_t need = 0;
+    if (gsr_l1_ssim_workspace(C, H, W, &need) != GSR_OK) return GSR_ERR_INVALID_ARGUMENT;
+    if (!img || !gt || !out3 || !ws) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_l1_ssim_forward: null pointer");
+    if (ws_bytes < need) return fail(GSR_ERR_WORKSPACE, "loss workspace %zu < %zu", ws_bytes, need);
+    float *dmaps = (float *)ws;
+    float *partial = (float *)((char *)ws + align_up((size_t)3 * C * H * W * sizeof(float)));
+    HIP_TRY(launch_l1_ssim_forward(C, H, W, img, gt, lambda_dssim, dmaps, partial, out3, (hipStream_t)stream), "l1+ssim forward launch");
+    return GSR_OK;
+}
+
+int32_t gsr_l1_ssim_backward(gsr_stream_t stream, int32_t C, int32_t H, int32_t W, const float *img, const float *gt,
+                             float lambda_dssim, const float *grad_loss, const void *ws, size_t ws_bytes, float *grad_img) {
+    size_t need = 0;
+    if (gsr_l1_ssim_workspace(C, H, W, &need) != GSR_OK) return GSR_ERR_INVALID_ARGUMENT;
+    if (!img || !gt || !ws || !grad_img) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_l1_ssim_backward: null pointer");
+    if (ws_bytes < need) return fail(GSR_ERR_WORKSPACE, "loss workspace %zu < %zu", ws_bytes, need);
+    HIP_TRY(launch_l1_ssim_backward(C, H, W, img, gt, lambda_dssim, (const float *)ws, grad_loss, grad_img, (hipStream_t)stream),
+            "l1+ssim backward launch");
     return GSR_OK;
 }
 

@@ -125,6 +125,11 @@ struct PergaussBwdArgs {
 };
 hipError_t launch_pergauss_bwd(const PergaussBwdArgs &a, hipStream_t s);
 
+hipError_t launch_l1_ssim_forward(int C, int H, int W, const float *img, const float *gt, float lambda, float *dmaps,
+                                  float *partial, float *out, hipStream_t s);
+hipError_t launch_l1_ssim_backward(int C, int H, int W, const float *img, const float *gt, float lambda, const float *dmaps,
+                                   const float *grad_loss, float *grad_img, hipStream_t s);
+
 hipError_t launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s);
 
 }  // namespace gsr

@@ -61,3 +61,52 @@ def psnr(img1: torch.Tensor, img2: torch.Tensor) -> torch.Tensor:
 def training_loss(image: torch.Tensor, gt_image: torch.Tensor, lambda_dssim: float = LAMBDA_DSSIM) -> torch.Tensor:
     """(1-lambda) L1 + lambda (1 - SSIM): train.py:91-92."""
     return (1.0 - lambda_dssim) * l1_loss(image, gt_image) + lambda_dssim * (1.0 - ssim(image, gt_image))
+
+
+class _FusedL1SSIM(torch.autograd.Function):
+    """(1-lambda) L1 + lambda (1-SSIM) in one HIP kernel per direction (include/gsr_loss.h)."""
+
+    @staticmethod
+    def forward(ctx, image, gt_image, lambda_dssim):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        dev = image.device
+        if dev.type != "cuda":
+            raise _lib.GsrError(f"fused_l1_ssim_loss needs tensors on a HIP device, got {dev} (use training_loss for the torch path)")
+        if image.dtype != torch.float32 or gt_image.dtype != torch.float32 or image.shape != gt_image.shape or image.dim() != 3:
+            raise _lib.GsrError("fused_l1_ssim_loss: image and gt_image must be float32 [C,H,W] tensors of equal shape")
+        img = image.contiguous(); gt = gt_image.to(dev).contiguous()
+        Cn, H, W = (int(x) for x in img.shape)
+        nb = C.c_size_t()
+        _lib.check(lib.gsr_l1_ssim_workspace(Cn, H, W, C.byref(nb)), "gsr_l1_ssim_workspace")
+        with torch.cuda.device(dev):
+            ws = torch.empty((nb.value,), dtype=torch.uint8, device=dev)
+            out = torch.empty((3,), dtype=torch.float32, device=dev)
+            _lib.check(lib.gsr_l1_ssim_forward(torch.cuda.current_stream(dev).cuda_stream, Cn, H, W, img.data_ptr(), gt.data_ptr(),
+                                               float(lambda_dssim), out.data_ptr(), ws.data_ptr(), nb.value), "gsr_l1_ssim_forward")
+        ctx.save_for_backward(img, gt, ws)
+        ctx.lambda_dssim = float(lambda_dssim)
+        ctx.terms = out
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        from . import _lib
+        lib = _lib.load()
+        img, gt, ws = ctx.saved_tensors
+        dev = img.device
+        Cn, H, W = (int(x) for x in img.shape)
+        with torch.cuda.device(dev):
+            g = grad_loss.to(device=dev, dtype=torch.float32).contiguous().reshape(1)
+            grad = torch.empty_like(img)
+            _lib.check(lib.gsr_l1_ssim_backward(torch.cuda.current_stream(dev).cuda_stream, Cn, H, W, img.data_ptr(), gt.data_ptr(),
+                                                ctx.lambda_dssim, g.data_ptr(), ws.data_ptr(), ws.numel(), grad.data_ptr()),
+                       "gsr_l1_ssim_backward")
+        return grad, None, None
+
+
+def fused_l1_ssim_loss(image: torch.Tensor, gt_image: torch.Tensor, lambda_dssim: float = LAMBDA_DSSIM) -> torch.Tensor:
+    """Drop-in for training_loss() on a HIP device: same value and gradient w.r.t. `image`
+    (gt_image gets no gradient, as in the reference's use at train.py:90-93)."""
+    return _FusedL1SSIM.apply(image, gt_image, lambda_dssim)

@@ -117,3 +117,14 @@ def test_loss_matches_reference_l1_ssim_psnr():
     L.backward()
     np.testing.assert_allclose(a.grad.numpy(), d["grad"], rtol=1e-4, atol=1e-9)
     np.testing.assert_allclose(loss.psnr(a.detach()[None], b[None]).numpy(), d["psnr"], rtol=1e-6)
+
+
+def test_numpy_loss_oracle_matches_reference_values_and_gradient():
+    """oracle/ssim_ref.py (the checker of the fused HIP loss) vs the reference's own l1/ssim/loss and autograd."""
+    from oracle import ssim_ref
+    d = np.load(os.path.join(G, "loss.npz"))
+    loss_v, l1, ssim, grad = ssim_ref.l1_ssim_loss(d["img1"], d["img2"], 0.2)
+    assert l1 == pytest.approx(float(d["l1"]), rel=1e-6)
+    assert ssim == pytest.approx(float(d["ssim"]), rel=1e-5)
+    assert loss_v == pytest.approx(float(d["loss"]), rel=1e-6)
+    np.testing.assert_allclose(grad, d["grad"], rtol=2e-4, atol=2e-9)
