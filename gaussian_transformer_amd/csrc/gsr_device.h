@@ -232,7 +232,9 @@ __device__ __forceinline__ CullParams make_cull(float A, float B, float C, float
 __device__ __forceinline__ void tile_row_span(const CullParams &c, float px, float py, float A, float B, int ty,
                                               int W, int H, int rx0, int rx1, int &c0, int &c1) {
     c0 = rx0; c1 = rx0;                                     // empty
-    if (!(c.tau > 0.f) || !(c.det > 0.f)) return;
+    if (!(c.tau > 0.f)) return;
+    if (!(c.det > 0.f) || !(A > 0.f)) { c1 = rx1; return; }  // not a positive-definite conic (only reachable with a
+                                                            // caller-supplied cov3D): no culling, upstream's rule
     const float ya = (float)(ty * GSR_TILE);
     const float yb = (float)min(ty * GSR_TILE + GSR_TILE - 1, H - 1);
     const float e0 = fmaxf(py - yb, -c.ymax), e1 = fminf(py - ya, c.ymax);   // dy = py - y over the band
@@ -256,6 +258,7 @@ __device__ __forceinline__ void tile_row_span(const CullParams &c, float px, flo
 // (d = splat centre - pixel); compared with the splat's culling threshold tau
 __device__ __forceinline__ bool block_reachable(float px, float py, float A, float B, float C, float invA, float invC,
                                                 float tau, float xa, float xb, float ya, float yb) {
+    if (!(A > 0.f) || !(C > 0.f) || !(A * C - B * B > 0.f)) return true;      // not positive definite: no culling
     const float dxa = px - xa, dxb = px - xb, dya = py - ya, dyb = py - yb;   // dxb <= dx <= dxa, dyb <= dy <= dya
     if (dxb <= 0.f && dxa >= 0.f && dyb <= 0.f && dya >= 0.f) return tau > 0.f;   // centre inside the block
     float q;
