@@ -196,6 +196,8 @@ def main():
                 "whole_path": {"alg_bytes_per_render": total_bytes,
                                "achieved_GBps": round(total_bytes * value / world / 1e9, 1),
                                "frac": round(total_bytes * value / world / 1e9 / HBM_PEAK_GBS, 4)},
+                "note": "compositing kernels are VALU-bound (PMC: 87-96 % VALU busy), not HBM-bound: SURVEY 8d; bytes are the "
+                        "algorithmic SURVEY figures with N = emitted pairs",
                 "stage_ms_fwd_total": round(stage_ms.get("fwd.total", 0.0), 4),
                 "stage_ms_bwd_total": round(stage_ms.get("bwd.total", 0.0), 4)}
 
@@ -215,7 +217,8 @@ def main():
         cpu = {"value": round(1.0 / (c2 - c0), 4), "unit": "renders/s", "cores": nt, "kind": "port",
                "sample": f"1 full forward+backward render of {args.config} (P={P}, {W}x{H}, N={f['num_rendered']}); "
                          f"forward {c1 - c0:.2f} s, backward {c2 - c1:.2f} s",
-               "fwd_s": round(c1 - c0, 3), "bwd_s": round(c2 - c1, 3)}
+               "fwd_s": round(c1 - c0, 3), "bwd_s": round(c2 - c1, 3),
+               "stage_s": {k: round(v, 4) for k, v in f["state"].timings().items()}}
         # same-run parity spot check of the bench inputs against the oracle
         cpu["rgb_max_abs_diff_vs_gpu"] = float(np.abs(state["color"].detach().cpu().numpy() - f["color"]).max())
 

@@ -102,6 +102,8 @@ typedef struct gsr_ref_state {
     /* image */
     REAL *final_T;
     uint32_t *n_contrib;
+    /* wall-clock seconds of the last forward / backward: preprocess, scan+emit+sort+ranges, composite | composite, per-Gaussian */
+    double t_fwd[3], t_bwd[2];
 } gsr_ref_state;
 
 /* x' = m[0]x + m[4]y + m[8]z + m[12]: the tensors are transposes stored row-major
@@ -273,6 +275,14 @@ static void radix_sort_pairs(uint64_t *k, uint32_t *v, int64_t n, int nbits) {
     free(k2); free(v2);
 }
 
+static double now_s(void) {
+#ifdef _OPENMP
+    return omp_get_wtime();
+#else
+    return 0.0;
+#endif
+}
+
 static int ceil_log2_u32(uint32_t x) { int b = 0; while ((1u << b) < x && b < 31) b++; return b; }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -299,6 +309,7 @@ gsr_ref_state *gsr_ref_forward(const gsr_ref_scene *sc, REAL *out_color, int32_t
 #endif
 
     /* ---- S1..S6 per Gaussian ---- */
+    double t0 = now_s();
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < P; i++) {
         radii[i] = 0; st->tiles_touched[i] = 0;
@@ -356,6 +367,7 @@ gsr_ref_state *gsr_ref_forward(const gsr_ref_scene *sc, REAL *out_color, int32_t
     }
 
     /* ---- scan ---- */
+    double t1 = now_s(); st->t_fwd[0] = t1 - t0;
     uint64_t run = 0;
     for (int i = 0; i < P; i++) { run += st->tiles_touched[i]; st->offsets[i] = (uint32_t)run; }
     const int64_t N = (int64_t)run; st->N = N;
@@ -386,6 +398,7 @@ gsr_ref_state *gsr_ref_forward(const gsr_ref_scene *sc, REAL *out_color, int32_t
     }
 
     /* ---- S9 compositing, per pixel front to back.  P == 0: image stays zero (not bg). ---- */
+    double t2 = now_s(); st->t_fwd[1] = t2 - t1;
     if (P == 0) { memset(out_color, 0, sizeof(REAL) * 3 * (size_t)W * H); return st; }
 #pragma omp parallel for schedule(dynamic, 1)
     for (int t = 0; t < T; t++) {
@@ -417,6 +430,7 @@ gsr_ref_state *gsr_ref_forward(const gsr_ref_scene *sc, REAL *out_color, int32_t
                 for (int ch = 0; ch < 3; ch++) out_color[(size_t)ch * W * H + pix] = C[ch] + Tr * sc->bg[ch];
             }
     }
+    st->t_fwd[2] = now_s() - t2;
     return st;
 }
 
@@ -428,7 +442,7 @@ static inline void atomic_add_real(REAL *p, REAL v) {
 /* ------------------------------------------------------------------------------------------ */
 /* backward: S10..S13.  All gradient buffers caller-owned and are OVERWRITTEN (zero-filled     */
 /* first).  dL_dconic is [P,4] scratch-visible (xx, xy(half), unused, yy) for stage tests.     */
-int gsr_ref_backward(const gsr_ref_scene *sc, const gsr_ref_state *st, const REAL *dL_dpix,
+int gsr_ref_backward(const gsr_ref_scene *sc, gsr_ref_state *st, const REAL *dL_dpix,
                      REAL *dL_dmeans2D /*[P,3]*/, REAL *dL_dconic /*[P,4]*/, REAL *dL_dopacity /*[P]*/,
                      REAL *dL_dcolors /*[P,3]*/, REAL *dL_dmeans3D /*[P,3]*/, REAL *dL_dcov3D /*[P,6]*/,
                      REAL *dL_dsh /*[P,M,3] or NULL*/, REAL *dL_dscales /*[P,3] or NULL*/, REAL *dL_drots /*[P,4] or NULL*/,
@@ -448,6 +462,7 @@ int gsr_ref_backward(const gsr_ref_scene *sc, const gsr_ref_state *st, const REA
     if (P == 0) return 0;
 
     /* ---- S10: per pixel, back to front from the last contributor ---- */
+    double tb0 = now_s();
 #pragma omp parallel for schedule(dynamic, 1)
     for (int t = 0; t < T; t++) {
         int tx = t % gridx, ty = t / gridx;
@@ -498,6 +513,7 @@ int gsr_ref_backward(const gsr_ref_scene *sc, const gsr_ref_state *st, const REA
     }
 
     /* ---- S11..S13 per Gaussian ---- */
+    double tb1 = now_s(); st->t_bwd[0] = tb1 - tb0;
     const int K = (sc->D + 1) * (sc->D + 1);
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < P; i++) {
@@ -601,6 +617,7 @@ int gsr_ref_backward(const gsr_ref_scene *sc, const gsr_ref_state *st, const REA
             dL_drots[4 * (size_t)i + 3] = R(2) * (-R(2) * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - R(2) * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
         }
     }
+    st->t_bwd[1] = now_s() - tb1;
     return 0;
 }
 
@@ -634,6 +651,10 @@ void gsr_ref_get_image_state(const gsr_ref_state *s, REAL *final_T, uint32_t *n_
     size_t n = (size_t)s->W * s->H;
     if (final_T) memcpy(final_T, s->final_T, sizeof(REAL) * n);
     if (n_contrib) memcpy(n_contrib, s->n_contrib, sizeof(uint32_t) * n);
+}
+void gsr_ref_get_timings(const gsr_ref_state *s, double *fwd3, double *bwd2) {
+    for (int i = 0; i < 3; i++) fwd3[i] = s->t_fwd[i];
+    for (int i = 0; i < 2; i++) bwd2[i] = s->t_bwd[i];
 }
 int32_t gsr_ref_real_bytes(void) { return (int32_t)sizeof(REAL); }
 int32_t gsr_ref_max_threads(void) {

@@ -93,6 +93,7 @@ class RefRasterizer:
         L.gsr_ref_get_image_state.argtypes = [C.c_void_p] * 3
         L.gsr_ref_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gsr_ref_max_threads.restype = C.c_int32
+        L.gsr_ref_get_timings.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         assert L.gsr_ref_real_bytes() == np.dtype(self.np_real).itemsize
 
     # -- helpers --
@@ -198,6 +199,13 @@ class _State:
         keys = np.zeros(max(N, 1), np.uint64); vals = np.zeros(max(N, 1), np.uint32); ranges = np.zeros((T, 2), np.uint32)
         self.owner.lib.gsr_ref_get_binning(self.handle, keys.ctypes.data, vals.ctypes.data, ranges.ctypes.data)
         return dict(keys=keys[:N], vals=vals[:N], ranges=ranges)
+
+    def timings(self) -> dict:
+        """Wall-clock seconds per stage of the last forward / backward on this state."""
+        f = (C.c_double * 3)(); b = (C.c_double * 2)()
+        self.owner.lib.gsr_ref_get_timings(self.handle, f, b)
+        return {"fwd.preprocess": f[0], "fwd.scan+emit+sort+ranges": f[1], "fwd.composite": f[2],
+                "bwd.composite": b[0], "bwd.pergauss": b[1]}
 
     def image_state(self) -> dict:
         r = self.owner.np_real
