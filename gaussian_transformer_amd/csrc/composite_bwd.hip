@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
             // v5..v7 = sum s*dx*dx, s*dx*dy, s*dy*dy (x -1/2 there), with s = o * G * dL/dalpha.
             float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
             const int pos = base + j;
-            bool any_ok = false;
+            unsigned long long any_ok = 0ull;         // 64-bit lane mask kept in SGPRs
             // body for one 8x8 block; straight-line so that the blocks of one splat interleave (ILP)
             auto block_body = [&](int q) __attribute__((always_inline)) {
                 const float dx = r0.x - fx[q], dy = r0.y - fy[q];
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
                 const float G = __builtin_amdgcn_exp2f(qf * (-0.5f * LOG2E));
                 const float alpha = fminf(GSR_ALPHA_MAX, r1.y * G);
                 const bool ok = (pos < last[q]) && !(qf < 0.f) && !(alpha < GSR_ALPHA_MIN);
-                any_ok = any_ok || ok;
+                any_ok |= __ballot(ok);
                 const float a_ok = ok ? alpha : 0.f;
                 const float inv = __builtin_amdgcn_rcpf(1.f - a_ok);
                 const float Tk = Tr[q] * inv;                        // transmittance in front of this splat
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
             v0 = r0.x * fx[0]; v8 = r1.y;
 #endif
 #ifndef GSR_ABL_NOREDUCE
-            if (!__any(any_ok)) continue;             // wave-uniform: no pixel of this wave blends the splat
+            if (any_ok == 0ull) continue;             // wave-uniform: no pixel of this wave blends the splat
             red[0 * 64 + lane] = v0; red[1 * 64 + lane] = v1; red[2 * 64 + lane] = v2;
             red[3 * 64 + lane] = v3; red[4 * 64 + lane] = v4; red[5 * 64 + lane] = v5;
             red[6 * 64 + lane] = v6; red[7 * 64 + lane] = v7; red[8 * 64 + lane] = v8;

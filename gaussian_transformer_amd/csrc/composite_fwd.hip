@@ -40,9 +40,11 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
     float4 *my = stage_dyn + wave * (64 * 3);
     const float4 *rec4 = reinterpret_cast<const float4 *>(a.rec);
 
+    // Tr > 0: transmittance of a live pixel;  Tr < 0: the pixel is finished and |Tr| is its final transmittance
+    // (a finished pixel then fails the T test of every later splat by itself: no separate flag to carry)
     float fx[NPX], fy[NPX], Tr[NPX], C0[NPX], C1[NPX], C2[NPX];
     uint32_t last[NPX];
-    bool done[NPX], inside[NPX];
+    bool inside[NPX];
     float bxa[NPX], bya[NPX], bxb[NPX], byb[NPX];
     bool all_done = true;
 #pragma unroll
@@ -54,15 +56,14 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
         fx[q] = (float)x; fy[q] = (float)y;
         bxa[q] = (float)x0; bya[q] = (float)y0;
         bxb[q] = (float)min(x0 + 7, a.W - 1); byb[q] = (float)min(y0 + 7, a.H - 1);
-        Tr[q] = 1.f; C0[q] = C1[q] = C2[q] = 0.f; last[q] = 0u;
-        done[q] = !inside[q];
-        all_done = all_done && done[q];
+        Tr[q] = inside[q] ? 1.f : -1.f; C0[q] = C1[q] = C2[q] = 0.f; last[q] = 0u;
+        all_done = all_done && !inside[q];
     }
 
     uint32_t blk_done = 0;                            // bit q: every pixel of block q is saturated (wave-uniform)
 #pragma unroll
     for (int q = 0; q < NPX; q++)
-        if (__all(done[q])) blk_done |= 1u << q;
+        if (__all(Tr[q] < 0.f)) blk_done |= 1u << q;
     for (int base = 0; base < n; base += 64) {
         if (__all(all_done)) break;                   // wave-uniform
         const int cnt = min(64, n - base);
@@ -94,30 +95,31 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
             const float4 r0 = my[j * 3 + 0], r1 = my[j * 3 + 1], r2 = my[j * 3 + 2];
             const uint32_t bits = __builtin_amdgcn_readfirstlane(__float_as_uint(r2.z));
             const uint32_t pos = (uint32_t)(base + j + 1);
-            bool any_stop = false;
+            unsigned long long any_stop = 0ull;       // lane mask in SGPRs
 #pragma unroll
             for (int q = 0; q < NPX; q++) {
                 if (!(bits & ~blk_done & (1u << q))) continue;    // scalar branch: unreachable or saturated block
                 const float dx = r0.x - fx[q], dy = r0.y - fy[q];
                 const float power = (r0.z * dx + r0.w * dy) * dx + (r1.x * dy) * dy;   // log2 units
                 const float alpha = fminf(GSR_ALPHA_MAX, r1.y * __builtin_amdgcn_exp2f(power));
-                const bool ok = !done[q] && !(power > 0.f) && !(alpha < GSR_ALPHA_MIN);
-                const float Tn = Tr[q] * (1.f - alpha);
+                const bool ok = !(power > 0.f) && !(alpha < GSR_ALPHA_MIN);
+                const float aT = alpha * Tr[q];
+                const float Tn = Tr[q] - aT;                         // = T (1 - alpha); negative for a finished pixel
                 const bool stop = ok && (Tn < GSR_T_MIN);
-                done[q] = done[q] || stop;
-                any_stop = any_stop || stop;
+                any_stop |= __ballot(stop && Tr[q] > 0.f);           // pixels finishing right now
                 const bool blend = ok && !stop;
-                const float w = blend ? alpha * Tr[q] : 0.f;
+                const float w = blend ? aT : 0.f;
                 C0[q] += r1.z * w; C1[q] += r1.w * w; C2[q] += r2.x * w;
-                Tr[q] = blend ? Tn : Tr[q];
+                Tr[q] = blend ? Tn : (stop ? -fabsf(Tr[q]) : Tr[q]);
                 last[q] = blend ? pos : last[q];
             }
-            if (__any(any_stop)) {                    // wave-uniform
+            if (any_stop != 0ull) {                   // wave-uniform
                 all_done = true;
 #pragma unroll
                 for (int q = 0; q < NPX; q++) {
-                    all_done = all_done && done[q];
-                    if (__all(done[q])) blk_done |= 1u << q;
+                    const bool dq = Tr[q] < 0.f;
+                    all_done = all_done && dq;
+                    if (__all(dq)) blk_done |= 1u << q;
                 }
                 if (__all(all_done)) { todo = 0; }
             }
@@ -129,11 +131,12 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
     for (int q = 0; q < NPX; q++) {
         if (inside[q]) {
             const size_t pix = (size_t)fy[q] * a.W + (size_t)fx[q];
-            a.final_T[pix] = Tr[q];
+            const float Tf = fabsf(Tr[q]);
+            a.final_T[pix] = Tf;
             a.n_contrib[pix] = last[q];
-            a.out_color[pix] = C0[q] + Tr[q] * bg0;
-            a.out_color[HW + pix] = C1[q] + Tr[q] * bg1;
-            a.out_color[2 * HW + pix] = C2[q] + Tr[q] * bg2;
+            a.out_color[pix] = C0[q] + Tf * bg0;
+            a.out_color[HW + pix] = C1[q] + Tf * bg1;
+            a.out_color[2 * HW + pix] = C2[q] + Tf * bg2;
         }
     }
 }
