@@ -52,12 +52,19 @@ hipError_t launch_sort(const BinningView &b, int64_t N, int bits, hipStream_t s)
 // ~20 small launches (~140 us) for 1 M Gaussians against ~5 launches for the radix passes.
 using DepthSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
 
+// below this size rocPRIM's default choice (single-block / merge sort) wins: 10 k items 15 us vs 118 us
+#define GSR_DEPTH_SORT_ONESWEEP_MIN 262144
+
 hipError_t depth_sort_temp_bytes(int P, size_t *bytes) {
-    size_t tb = 0;
+    size_t tb = 0, tb2 = 0;
+    hipError_t e2 = rocprim::radix_sort_pairs(nullptr, tb2, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                              rocprim::counting_iterator<uint32_t>(0), (uint32_t *)nullptr,
+                                              (size_t)(P > 0 ? P : 1), 0u, 32u, (hipStream_t)0, false);
+    if (e2 != hipSuccess) return e2;
     hipError_t e = rocprim::radix_sort_pairs<DepthSortConfig>(nullptr, tb, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                              rocprim::counting_iterator<uint32_t>(0), (uint32_t *)nullptr,
                                              (size_t)(P > 0 ? P : 1), 0u, 32u, (hipStream_t)0, false);
-    *bytes = tb;
+    *bytes = tb > tb2 ? tb : tb2;
     return e;
 }
 
@@ -66,6 +73,9 @@ hipError_t depth_sort_temp_bytes(int P, size_t *bytes) {
 // radix passes just queue behind preprocess's resident workgroups, no overlap -- kept on one stream.)
 hipError_t launch_depth_sort(const GeomView &g, int P, hipStream_t s) {
     size_t tb = g.dsort_temp_bytes;
+    if (P < GSR_DEPTH_SORT_ONESWEEP_MIN)
+        return rocprim::radix_sort_pairs(g.dsort_temp, tb, reinterpret_cast<const uint32_t *>(g.depth), g.depth_sorted,
+                                         rocprim::counting_iterator<uint32_t>(0), g.perm, (size_t)P, 0u, 32u, s, false);
     return rocprim::radix_sort_pairs<DepthSortConfig>(g.dsort_temp, tb, reinterpret_cast<const uint32_t *>(g.depth), g.depth_sorted,
                                                       rocprim::counting_iterator<uint32_t>(0), g.perm, (size_t)P, 0u, 32u, s, false);
 }
