@@ -32,14 +32,16 @@ SIGNATURES = {
                            _p, _p, _p, _f, _f,                        # view proj campos tanfovx tanfovy
                            _i32, _i32, _p, _p,                        # prefiltered debug out_color radii
                            _p, _sz, ALLOC_FN, _p, _p, _sz,            # geom, bytes, alloc, user, img, bytes
-                           C.POINTER(C.c_int64)]),
+                           C.POINTER(C.c_int64),
+                           _p, _i32]),                                # shs_rest raw_params (fused-step extension)
     "gsr_backward": (_i32, [_p, _i32, _i32, _i32, C.c_int64, _i32, _i32,   # stream P D M R W H
                             _p, _p, _p, _p, _p,                       # bg means3D radii shs colors
                             _p, _f, _p, _p,                           # scales mod rotations cov3D
                             _p, _p, _p, _f, _f,                       # view proj campos tanfovx tanfovy
                             _p, _p, _sz, _p, _sz, _p, _sz, _p, _sz,   # dL_dpix geom binning img bwd (+bytes)
                             _p, _p, _p, _p, _p, _p, _p, _p,           # 8 gradient outputs
-                            _i32]),
+                            _i32,                                     # debug
+                            _p, _i32, _p]),                           # shs_rest raw_params dL_dsh_rest
     "gsr_mark_visible": (_i32, [_p, _i32, _p, _p, _p, _p]),
     "gsr_debug_read_geom": (_i32, [_p, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "gsr_debug_read_binning": (_i32, [_p, C.c_int64, _i32, _i32, _p, _p, _p, _p, _p]),
@@ -83,8 +85,8 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)       # AttributeError if the symbol is missing: loud by design
             fn.restype = res
             fn.argtypes = args
-        if lib.gsr_abi_version() != 1:
-            raise GsrError(f"libgsr_hip.so ABI version {lib.gsr_abi_version()} != 1")
+        if lib.gsr_abi_version() != 2:
+            raise GsrError(f"libgsr_hip.so ABI version {lib.gsr_abi_version()} != 2")
         _lib = lib
     return _lib
 

@@ -207,7 +207,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
                     const float *viewmatrix, const float *projmatrix, const float *campos, float tanfovx,
                     float tanfovy, int32_t prefiltered, int32_t debug, float *out_color, int32_t *radii, void *geom_ws,
                     size_t geom_bytes, gsr_alloc_fn binning_alloc, void *binning_user, void *img_ws, size_t img_bytes,
-                    int64_t *num_rendered) {
+                    int64_t *num_rendered, const float *shs_rest, int32_t raw_params) {
     (void)prefiltered;   // culled Gaussians are always skipped, as with prefiltered=False (the only value the reference passes)
     hipStream_t s = (hipStream_t)stream;
     if (num_rendered) *num_rendered = 0;
@@ -225,6 +225,8 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
         return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward: exactly one of shs / colors_precomp must be given");
     if (((scales != nullptr) && (rotations != nullptr)) == (cov3D_precomp != nullptr) || ((scales != nullptr) != (rotations != nullptr)))
         return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward: exactly one of (scales, rotations) / cov3D_precomp must be given");
+    if (shs_rest && (!shs || M < 2)) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward: shs_rest needs shs (= features_dc) and M >= 2");
+    if (raw_params && cov3D_precomp) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward: raw_params needs scales/rotations, not cov3D_precomp");
     if (shs) {
         if (D < 0 || D > 3) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward: SH degree %d not in 0..3", D);
         if (M < (D + 1) * (D + 1)) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward: M=%d < (D+1)^2=%d", M, (D + 1) * (D + 1));
@@ -243,6 +245,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     tm.mark(0);
     PreprocessArgs pa;
     pa.P = P; pa.D = D; pa.M = M; pa.W = W; pa.H = H; pa.gridx = gridx; pa.gridy = gridy;
+    pa.raw_params = raw_params ? 1 : 0; pa.shs_rest = shs_rest;
     pa.means3D = means3D; pa.shs = shs; pa.colors_precomp = colors_precomp; pa.opacities = opacities;
     pa.scales = scales; pa.rotations = rotations; pa.cov3D_precomp = cov3D_precomp;
     pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.campos = campos;
@@ -298,7 +301,8 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
                      float tanfovx, float tanfovy, const float *dL_dpix, const void *geom_ws, size_t geom_bytes,
                      const void *binning_ws, size_t binning_bytes, const void *img_ws, size_t img_bytes, void *bwd_ws,
                      size_t bwd_bytes, float *dL_dmeans2D, float *dL_dopacity, float *dL_dcolors, float *dL_dmeans3D,
-                     float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drots, int32_t debug) {
+                     float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drots, int32_t debug,
+                     const float *shs_rest, int32_t raw_params, float *dL_dsh_rest) {
     hipStream_t s = (hipStream_t)stream;
     if (P < 0 || W <= 0 || H <= 0 || R < 0) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: bad sizes");
     if (P == 0) return GSR_OK;
@@ -312,6 +316,8 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     if (shs && (!dL_dsh || !campos || D < 0 || D > 3 || M < (D + 1) * (D + 1)))
         return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: SH inputs inconsistent");
     if (scales && (!dL_dscales || !dL_drots)) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: dL_dscales/dL_drots required");
+    if (shs_rest && (!shs || !dL_dsh_rest || M < 2)) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: shs_rest needs shs, dL_dsh_rest and M >= 2");
+    if (raw_params && cov3D_precomp) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: raw_params needs scales/rotations");
     if (R > 0 && !binning_ws) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: binning workspace missing");
     size_t stb = 0, dtb = 0;
     HIP_TRY(scan_temp_bytes(P, &stb), "scan temp query");
@@ -341,6 +347,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     }
     tm.mark(10);
     PergaussBwdArgs pa;
+    pa.raw_params = raw_params ? 1 : 0; pa.shs_rest = shs_rest; pa.rec = g.rec; pa.dL_dsh_rest = dL_dsh_rest;
     pa.P = P; pa.D = D; pa.M = M; pa.W = W; pa.H = H; pa.means3D = means3D; pa.shs = shs; pa.colors_precomp = colors_precomp;
     pa.scales = scales; pa.rotations = rotations; pa.cov3D_precomp = cov3D_precomp; pa.viewmatrix = viewmatrix;
     pa.projmatrix = projmatrix; pa.campos = campos; pa.scale_modifier = scale_modifier; pa.tanfovx = tanfovx;

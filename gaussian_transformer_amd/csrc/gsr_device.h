@@ -297,4 +297,23 @@ __device__ __forceinline__ void load_sh_row(const float *__restrict__ shs, size_
     }
 }
 
+// SH row given as two tensors, as the reference stores them (scene/gaussian_model.py:108-111):
+// dc [P,1,3] holds coefficient 0, rest [P,M-1,3] holds coefficients 1..M-1.  Avoids the torch.cat.
+template <int K>
+__device__ __forceinline__ void load_sh_row_split(const float *__restrict__ dc, const float *__restrict__ rest, size_t i,
+                                                  int M, float c[3 * K + 3]) {
+    c[0] = dc[3 * i]; c[1] = dc[3 * i + 1]; c[2] = dc[3 * i + 2];
+    const float *row = rest + i * (size_t)(M - 1) * 3;
+#pragma unroll
+    for (int v = 3; v < 3 * K; v++) c[v] = row[v - 3];
+}
+
+// activations of scene/gaussian_model.py:33-41 for the fused (raw parameter) path
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ void act_normalize4(float q[4], float &inv_norm) {     // F.normalize: x / max(|x|, 1e-12)
+    const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    inv_norm = 1.f / fmaxf(n, 1e-12f);
+    q[0] *= inv_norm; q[1] *= inv_norm; q[2] *= inv_norm; q[3] *= inv_norm;
+}
+
 }  // namespace gsr

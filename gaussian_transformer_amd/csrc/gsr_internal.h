@@ -66,6 +66,8 @@ BinningView carve_binning(void *base, int64_t N, size_t sort_temp_bytes);
 
 struct PreprocessArgs {
     int P, D, M, W, H, gridx, gridy;
+    int raw_params;          // 1: opacities are logits, scales are log-scales, rotations are un-normalised
+    const float *shs_rest;   // non-NULL: shs is the DC tensor [P,1,3], shs_rest is [P,M-1,3]
     const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     const float *viewmatrix, *projmatrix, *campos;
     float scale_modifier, tanfovx, tanfovy;
@@ -115,6 +117,10 @@ hipError_t launch_composite_bwd(const CompositeBwdArgs &a, int npx, int exact_cu
 
 struct PergaussBwdArgs {
     int P, D, M, W, H;
+    int raw_params;
+    const float *shs_rest;
+    const float *rec;        // forward record (activated opacity at [5])
+    float *dL_dsh_rest;
     const float *means3D, *shs, *colors_precomp, *scales, *rotations, *cov3D_precomp;
     const float *viewmatrix, *projmatrix, *campos;
     float scale_modifier, tanfovx, tanfovy;

@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
     float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dcol[3] = {0.f, 0.f, 0.f}, dm2[2] = {0.f, 0.f}, dop = 0.f;
     float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
+    float q_inv_norm = 1.f;
 
     if (visible) {
         const float4 *acc4 = reinterpret_cast<const float4 *>(a.acc) + 4 * si;
@@ -44,6 +45,10 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
             s[0] = a.scales[3 * si]; s[1] = a.scales[3 * si + 1]; s[2] = a.scales[3 * si + 2];
             const float4 q4 = reinterpret_cast<const float4 *>(a.rotations)[si];
             q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+            if (a.raw_params) {
+                s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]);
+                act_normalize4(q, q_inv_norm);
+            }
             cov3d_from_scale_rot(s, a.scale_modifier, q, c6);
         }
         // ---- S11 ----
@@ -102,10 +107,11 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
             sh_basis<D>(dir, bas);
             sh_basis_grad<D>(dir, bg3);
             float c[3 * K + 3];
-            load_sh_row<K>(a.shs, si, a.M, c);
+            if (a.shs_rest) load_sh_row_split<K>(a.shs, a.shs_rest, si, a.M, c);
+            else load_sh_row<K>(a.shs, si, a.M, c);
             const uint8_t cl = a.clamped[si];
             float ddir[3] = {0.f, 0.f, 0.f};
-            float *out = a.dL_dsh + si * (size_t)a.M * 3;
+            float *out = a.shs_rest ? nullptr : a.dL_dsh + si * (size_t)a.M * 3;
             float gch[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) gch[ch] = ((cl >> ch) & 1) ? 0.f : dcol[ch];
@@ -115,11 +121,21 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
                 for (int k = 0; k < K; k++)
 #pragma unroll
                     for (int ax = 0; ax < 3; ax++) ddir[ax] += bg3[k][ax] * c[k * 3 + ch] * gch[ch];
+            if (!a.shs_rest) {
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                out[k * 3 + 0] = bas[k] * gch[0]; out[k * 3 + 1] = bas[k] * gch[1]; out[k * 3 + 2] = bas[k] * gch[2];
+                for (int k = 0; k < K; k++) {
+                    out[k * 3 + 0] = bas[k] * gch[0]; out[k * 3 + 1] = bas[k] * gch[1]; out[k * 3 + 2] = bas[k] * gch[2];
+                }
+                for (int k = 3 * K; k < 3 * a.M; k++) out[k] = 0.f;
+            } else {                                   // dc [P,1,3] and rest [P,M-1,3] written separately
+                float *odc = a.dL_dsh + 3 * si, *orest = a.dL_dsh_rest + si * (size_t)(a.M - 1) * 3;
+                odc[0] = bas[0] * gch[0]; odc[1] = bas[0] * gch[1]; odc[2] = bas[0] * gch[2];
+#pragma unroll
+                for (int k = 1; k < K; k++) {
+                    orest[(k - 1) * 3 + 0] = bas[k] * gch[0]; orest[(k - 1) * 3 + 1] = bas[k] * gch[1]; orest[(k - 1) * 3 + 2] = bas[k] * gch[2];
+                }
+                for (int k = 3 * (K - 1); k < 3 * (a.M - 1); k++) orest[k] = 0.f;
             }
-            for (int k = 3 * K; k < 3 * a.M; k++) out[k] = 0.f;
             const float dot = dir[0] * ddir[0] + dir[1] * ddir[1] + dir[2] * ddir[2];
 #pragma unroll
             for (int ax = 0; ax < 3; ax++) dmean[ax] += (ddir[ax] - dir[ax] * dot) * il;
@@ -155,9 +171,25 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
             drot[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
             drot[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
         }
+        if (a.raw_params) {                            // chain through sigmoid / exp / normalize (scene/gaussian_model.py:33-41)
+            const float o = a.rec[GSR_REC_FLOATS * si + 5];
+            dop *= o * (1.f - o);
+            if (!a.cov3D_precomp) {
+                dscale[0] *= s[0]; dscale[1] *= s[1]; dscale[2] *= s[2];
+                const float dotq = q[0] * drot[0] + q[1] * drot[1] + q[2] * drot[2] + q[3] * drot[3];
+#pragma unroll
+                for (int k = 0; k < 4; k++) drot[k] = (drot[k] - q[k] * dotq) * q_inv_norm;
+            }
+        }
     } else if (a.shs) {
-        float *out = a.dL_dsh + si * (size_t)a.M * 3;
-        for (int k = 0; k < 3 * a.M; k++) out[k] = 0.f;
+        if (!a.shs_rest) {
+            float *out = a.dL_dsh + si * (size_t)a.M * 3;
+            for (int k = 0; k < 3 * a.M; k++) out[k] = 0.f;
+        } else {
+            float *odc = a.dL_dsh + 3 * si, *orest = a.dL_dsh_rest + si * (size_t)(a.M - 1) * 3;
+            odc[0] = odc[1] = odc[2] = 0.f;
+            for (int k = 0; k < 3 * (a.M - 1); k++) orest[k] = 0.f;
+        }
     }
 
     a.dL_dmeans2D[3 * si] = dm2[0]; a.dL_dmeans2D[3 * si + 1] = dm2[1]; a.dL_dmeans2D[3 * si + 2] = 0.f;

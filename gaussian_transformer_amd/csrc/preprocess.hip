@@ -35,9 +35,14 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreprocessArgs a) {
 #pragma unroll
             for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * si + k];
         } else {                                                                    // S2
-            const float s[3] = {a.scales[3 * si], a.scales[3 * si + 1], a.scales[3 * si + 2]};
+            float s[3] = {a.scales[3 * si], a.scales[3 * si + 1], a.scales[3 * si + 2]};
             const float4 q4 = reinterpret_cast<const float4 *>(a.rotations)[si];
-            const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+            float q[4] = {q4.x, q4.y, q4.z, q4.w};
+            if (a.raw_params) {                       // fused activations: exp / normalize
+                s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]);
+                float inv_norm;
+                act_normalize4(q, inv_norm);
+            }
             cov3d_from_scale_rot(s, a.scale_modifier, q, c6);
         }
         Ewa e;
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreprocessArgs a) {
             tile_rect(px, py, radius, a.gridx, a.gridy, x0, y0, x1, y1);
             const int area = (x1 - x0) * (y1 - y0);
             if (area != 0) {
-                const float opacity = a.opacities[si];
+                const float opacity = a.raw_params ? act_sigmoid(a.opacities[si]) : a.opacities[si];
                 float tau = 0.f;
                 int pairs = area;
                 if (a.exact_cull) {                      // count only the tiles the ellipse can reach
@@ -82,7 +87,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreprocessArgs a) {
                     sh_basis<D>(dir, b);
                     constexpr int K = (D + 1) * (D + 1);
                     float c[3 * K + 3];
-                    load_sh_row<K>(a.shs, si, a.M, c);
+                    if (a.shs_rest) load_sh_row_split<K>(a.shs, a.shs_rest, si, a.M, c);
+                    else load_sh_row<K>(a.shs, si, a.M, c);
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
                         float v = 0.f;

@@ -66,12 +66,14 @@ class HipBackend:
         return v
 
     def forward(self, rs: GaussianRasterizationSettings, means3D, shs, colors_precomp, opacities, scales, rotations,
-                cov3D_precomp):
+                cov3D_precomp, shs_rest=None, raw_params=False):
         dev = means3D.device
         if dev.type != "cuda":
             raise _lib.GsrError(f"the HIP rasterizer needs tensors on a HIP device, got {dev} (no CPU fallback)")
         P, H, W = int(means3D.shape[0]), int(rs.image_height), int(rs.image_width)
         M = int(shs.shape[1]) if shs.numel() else 0
+        if shs_rest is not None:
+            M += int(shs_rest.shape[1])
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             gb, ib, _ = self._sizes(P, W, H)
@@ -98,16 +100,17 @@ class HipBackend:
                 _ptr(opacities), _ptr(scales), float(rs.scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
                 _ptr(vm), _ptr(pm), _ptr(cp), float(rs.tanfovx), float(rs.tanfovy), int(bool(rs.prefiltered)),
                 int(bool(rs.debug)), color.data_ptr(), _ptr(radii), geom.data_ptr(), gb, cb, None, img.data_ptr(), ib,
-                C.byref(n))
+                C.byref(n), _ptr(shs_rest), int(bool(raw_params)))
             _lib.check(rc, "gsr_forward")
             binning = holder[0] if holder else torch.empty((0,), **u8)
         return int(n.value), color, radii, geom, binning, img
 
     def backward(self, rs, num_rendered, dL_dpix, means3D, radii, shs, colors_precomp, scales, rotations,
-                 cov3D_precomp, geom, binning, img):
+                 cov3D_precomp, geom, binning, img, shs_rest=None, raw_params=False):
         dev = means3D.device
         P, H, W = int(means3D.shape[0]), int(rs.image_height), int(rs.image_width)
         M = int(shs.shape[1]) if shs.numel() else 0
+        Mrest = int(shs_rest.shape[1]) if shs_rest is not None else 0
         f32 = dict(dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
@@ -132,6 +135,7 @@ class HipBackend:
                 return v
             g_means3D = out((P, 3))
             g_sh = out((P, M, 3)) if M > 0 else torch.empty((0,), **f32)
+            g_sh_rest = out((P, Mrest, 3)) if Mrest > 0 else None
             g_opacity = out((P, 1))
             g_scales = out((P, 3)) if has_sr else torch.empty((0,), **f32)
             g_rots = out((P, 4)) if has_sr else torch.empty((0,), **f32)
@@ -141,13 +145,16 @@ class HipBackend:
             pm = _f32c(rs.projmatrix, "projmatrix", dev); cp = _f32c(rs.campos, "campos", dev)
             dL = _f32c(dL_dpix, "grad of rendered image", dev)
             rc = self.lib.gsr_backward(
-                stream, P, int(rs.sh_degree), M, int(num_rendered), W, H, _ptr(bg), _ptr(means3D), _ptr(radii),
+                stream, P, int(rs.sh_degree), M + Mrest, int(num_rendered), W, H, _ptr(bg), _ptr(means3D), _ptr(radii),
                 _ptr(shs), _ptr(colors_precomp), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
                 _ptr(cov3D_precomp), _ptr(vm), _ptr(pm), _ptr(cp), float(rs.tanfovx), float(rs.tanfovy), _ptr(dL),
                 _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(), _ptr(bwd_ws),
                 bwd_ws.numel(), _ptr(g_means2D), _ptr(g_opacity), _ptr(g_colors), _ptr(g_means3D), _ptr(g_cov3D),
-                _ptr(g_sh), _ptr(g_scales), _ptr(g_rots), int(bool(rs.debug)))
+                _ptr(g_sh), _ptr(g_scales), _ptr(g_rots), int(bool(rs.debug)), _ptr(shs_rest), int(bool(raw_params)),
+                _ptr(g_sh_rest))
             _lib.check(rc, "gsr_backward")
+        if shs_rest is not None:
+            return g_means3D, g_means2D, g_sh, g_colors, g_opacity, g_scales, g_rots, g_cov3D, g_sh_rest
         return g_means3D, g_means2D, g_sh, g_colors, g_opacity, g_scales, g_rots, g_cov3D
 
     def mark_visible(self, positions, viewmatrix, projmatrix):
@@ -264,6 +271,47 @@ class _RasterizeGaussians(torch.autograd.Function):
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings)
+
+
+class _RasterizeGaussiansFused(torch.autograd.Function):
+    """Fused-step variant: takes the RAW parameters of scene/gaussian_model.py (xyz, features_dc,
+    features_rest, opacity logits, log-scales, un-normalised quaternions); the activations (:33-41) and the
+    torch.cat of get_features (:108-111) happen inside the per-Gaussian kernels, forward and backward."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings):
+        be = get_backend()
+        dev = means3D.device
+        if means3D.dim() != 2 or means3D.shape[1] != 3:
+            raise _lib.GsrError("means3D must have dimensions (num_points, 3)")
+        a = [_f32c(t, n, dev) for t, n in ((means3D, "means3D"), (features_dc, "features_dc"), (features_rest, "features_rest"),
+                                            (opacity_raw, "opacity"), (scaling_raw, "scaling"), (rotation_raw, "rotation"))]
+        m3, dc, rest, op, sc, rot = a
+        if dc.dim() != 3 or dc.shape[1] != 1 or rest.dim() != 3 or rest.shape[1] < 1:
+            raise _lib.GsrError("features_dc must be [P,1,3] and features_rest [P,M-1,3] with M >= 2")
+        empty = m3.new_empty((0,))
+        num_rendered, color, radii, geom, binning, img = be.forward(raster_settings, m3, dc, empty, op, sc, rot, empty,
+                                                                    shs_rest=rest, raw_params=True)
+        ctx.raster_settings, ctx.num_rendered = raster_settings, num_rendered
+        ctx.save_for_backward(m3, dc, rest, sc, rot, radii, geom, binning, img)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        be = get_backend()
+        m3, dc, rest, sc, rot, radii, geom, binning, img = ctx.saved_tensors
+        empty = m3.new_empty((0,))
+        g_m3, g_m2, g_dc, _g_col, g_op, g_sc, g_rot, _g_cov, g_rest = be.backward(
+            ctx.raster_settings, ctx.num_rendered, grad_out_color, m3, radii, dc, empty, sc, rot, empty, geom, binning, img,
+            shs_rest=rest, raw_params=True)
+        return g_m3, g_m2, g_dc, g_rest, g_op, g_sc, g_rot, None
+
+
+def rasterize_gaussians_fused(means3D, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings):
+    """(color, radii) from the raw Gaussian parameters; gradients flow to the raw parameters."""
+    return _RasterizeGaussiansFused.apply(means3D, means2D, features_dc, features_rest, opacity_raw, scaling_raw,
+                                          rotation_raw, raster_settings)
 
 
 class GaussianRasterizer(nn.Module):

@@ -13,7 +13,7 @@ from dataclasses import dataclass
 
 import torch
 
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_fused
 
 
 @dataclass
@@ -82,6 +82,28 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier:
     rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
                                        opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
+
+
+def render_fused(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier: float = 1.0):
+    """Same result dict as render(), through the fused-step entry point: the raw parameters
+    of the model go straight to the kernels -- no exp / sigmoid / normalize / cat tensors, no autograd nodes
+    for them.  Only the default configuration of render() (SH colours, scale/rotation covariance) is
+    covered; use render() for override_color / convert_SHs_python / compute_cov3D_python."""
+    xyz = pc._xyz
+    screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    rs = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,
+        scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
+    image, radii = rasterize_gaussians_fused(xyz, screenspace_points, pc._features_dc, pc._features_rest, pc._opacity,
+                                             pc._scaling, pc._rotation, rs)
+    return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
 
 
 class TorchCamera:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 1
+#define GSR_ABI_VERSION 2
 
 enum {
     GSR_OK = 0,
@@ -81,7 +81,12 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
                     const float *projmatrix /*[16]*/, const float *campos /*[3]*/, float tanfovx, float tanfovy,
                     int32_t prefiltered, int32_t debug, float *out_color /*[3,H,W]*/, int32_t *radii /*[P]*/,
                     void *geom_ws, size_t geom_bytes, gsr_alloc_fn binning_alloc, void *binning_user,
-                    void *img_ws, size_t img_bytes, int64_t *num_rendered /*host*/);
+                    void *img_ws, size_t img_bytes, int64_t *num_rendered /*host*/,
+                    /* fused-step extension, pass NULL / 0 for the reference's behaviour: */
+                    const float *shs_rest /* non-NULL: `shs` is features_dc [P,1,3], this is features_rest [P,M-1,3]
+                                             (scene/gaussian_model.py:108-111 without the torch.cat) */,
+                    int32_t raw_params /* 1: opacities are logits, scales log-scales, rotations un-normalised; the
+                                          activations of scene/gaussian_model.py:33-41 are applied in-kernel */);
 
 /* Backward: reverse compositing (S10) + per-Gaussian chain (S11-S13).
  *   R = num_rendered of the matching forward; geom_ws / binning_ws / img_ws as the forward left
@@ -99,7 +104,11 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
                      const void *binning_ws, size_t binning_bytes, const void *img_ws, size_t img_bytes,
                      void *bwd_ws, size_t bwd_bytes, float *dL_dmeans2D, float *dL_dopacity, float *dL_dcolors,
                      float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drots,
-                     int32_t debug);
+                     int32_t debug,
+                     /* fused-step extension: same meaning as in gsr_forward.  With shs_rest, dL_dsh is [P,1,3] and
+                      * dL_dsh_rest [P,M-1,3]; with raw_params, dL_dopacity / dL_dscales / dL_drots are gradients
+                      * w.r.t. the raw (pre-activation) parameters. */
+                     const float *shs_rest, int32_t raw_params, float *dL_dsh_rest);
 
 /* present[i] = 1 iff Gaussian i passes the near-plane test (view z > 0.2). */
 int32_t gsr_mark_visible(gsr_stream_t stream, int32_t P, const float *means3D, const float *viewmatrix,

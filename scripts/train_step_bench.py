@@ -14,7 +14,7 @@ import torch
 from gaussian_transformer_amd import synth
 from gaussian_transformer_amd.loss import fused_l1_ssim_loss, training_loss
 from gaussian_transformer_amd.model import GaussianParams
-from gaussian_transformer_amd.render import PipelineParams, TorchCamera, render
+from gaussian_transformer_amd.render import PipelineParams, TorchCamera, render, render_fused
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="cfg3_synth_1M_1080p")
@@ -22,6 +22,7 @@ ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--loss", choices=["fused", "torch"], default="fused", help="fused = HIP L1+SSIM kernel (include/gsr_loss.h); torch = grouped conv2d path")
 ap.add_argument("--adam", choices=["fused", "default"], default="fused")
+ap.add_argument("--render", choices=["fused", "reference"], default="fused", help="fused = raw parameters into the kernels (render_fused)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 sc = synth.make_config(a.config)
@@ -33,6 +34,7 @@ lrs = [0.00016, 0.0025, 0.0025 / 20.0, 0.05, 0.005, 0.001]          # arguments/
 opt = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(pc.parameters(), lrs)], lr=0.0, eps=1e-15,
                        **({"fused": True} if a.adam == "fused" else {}))
 training_loss = fused_l1_ssim_loss if a.loss == "fused" else training_loss
+render = render_fused if a.render == "fused" else render
 pipe = PipelineParams()
 parts = {"render": 0.0, "loss": 0.0, "backward": 0.0, "adam": 0.0}
 ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -63,6 +65,6 @@ for it in range(a.iters):
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(json.dumps({"metric": "full optimisation steps/s (render + L1/SSIM loss + backward + Adam)", "value": round(a.iters / dt, 2),
-                  "ms_per_iter": round(dt / a.iters * 1e3, 3), "config": a.config, "loss_impl": a.loss, "adam_impl": a.adam,
+                  "ms_per_iter": round(dt / a.iters * 1e3, 3), "config": a.config, "loss_impl": a.loss, "adam_impl": a.adam, "render_impl": a.render,
                   "ms_breakdown": {k: round(v / a.iters, 3) for k, v in parts.items()},
                   "loss_first": round(losses[0], 5), "loss_last": round(losses[-1], 5)}))

@@ -45,19 +45,19 @@ int main(void) {
     int64_t n = -1;
     /* error paths first: they must return codes, not abort, and leave the device usable */
     int rc = gsr_forward(NULL, P, D, M, W, H, d_bg, d_means, d_shs, d_shs, d_op, d_sc, 1.f, d_rot, NULL, d_view, d_proj, d_cam, tanx, tany, 0, 0,
-                         color, radii, geom, gb, alloc_cb, NULL, img, ib, &n);
+                         color, radii, geom, gb, alloc_cb, NULL, img, ib, &n, NULL, 0);
     if (rc != GSR_ERR_INVALID_ARGUMENT) { printf("expected INVALID_ARGUMENT for shs+colors, got %d\n", rc); return 1; }
     rc = gsr_forward(NULL, P, D, M, W, H, d_bg, d_means, d_shs, NULL, d_op, d_sc, 1.f, d_rot, NULL, d_view, d_proj, d_cam, tanx, tany, 0, 0,
-                     color, radii, geom, gb / 2, alloc_cb, NULL, img, ib, &n);
+                     color, radii, geom, gb / 2, alloc_cb, NULL, img, ib, &n, NULL, 0);
     if (rc != GSR_ERR_WORKSPACE) { printf("expected WORKSPACE, got %d\n", rc); return 1; }
     g_fail_alloc = 1;
     rc = gsr_forward(NULL, P, D, M, W, H, d_bg, d_means, d_shs, NULL, d_op, d_sc, 1.f, d_rot, NULL, d_view, d_proj, d_cam, tanx, tany, 0, 0,
-                     color, radii, geom, gb, alloc_cb, NULL, img, ib, &n);
+                     color, radii, geom, gb, alloc_cb, NULL, img, ib, &n, NULL, 0);
     if (rc != GSR_ERR_ALLOC || strlen(gsr_last_error()) == 0) { printf("expected ALLOC with a message, got %d\n", rc); return 1; }
     g_fail_alloc = 0;
     /* the real call, debug = 1 (synchronises after every stage) */
     rc = gsr_forward(NULL, P, D, M, W, H, d_bg, d_means, d_shs, NULL, d_op, d_sc, 1.f, d_rot, NULL, d_view, d_proj, d_cam, tanx, tany, 0, 1,
-                     color, radii, geom, gb, alloc_cb, NULL, img, ib, &n);
+                     color, radii, geom, gb, alloc_cb, NULL, img, ib, &n, NULL, 0);
     if (rc != GSR_OK) { printf("forward failed: %s\n", gsr_last_error()); return 1; }
     float *h_color = (float *)malloc(3 * W * H * 4); int32_t h_r[3];
     CK(hipMemcpy(h_color, color, 3 * W * H * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h_r, radii, 12, hipMemcpyDeviceToHost));
@@ -71,7 +71,7 @@ int main(void) {
     CK(hipMalloc((void **)&g2, P * 12)); CK(hipMalloc((void **)&go, P * 4)); CK(hipMalloc((void **)&gc, P * 12)); CK(hipMalloc((void **)&g3, P * 12));
     CK(hipMalloc((void **)&gcov, P * 24)); CK(hipMalloc((void **)&gsh, P * M * 12)); CK(hipMalloc((void **)&gs, P * 12)); CK(hipMalloc((void **)&gr, P * 16));
     rc = gsr_backward(NULL, P, D, M, n, W, H, d_bg, d_means, radii, d_shs, NULL, d_sc, 1.f, d_rot, NULL, d_view, d_proj, d_cam, tanx, tany, d_dl,
-                      geom, gb, g_bin, g_bin_bytes, img, ib, bwd, bb, g2, go, gc, g3, gcov, gsh, gs, gr, 1);
+                      geom, gb, g_bin, g_bin_bytes, img, ib, bwd, bb, g2, go, gc, g3, gcov, gsh, gs, gr, 1, NULL, 0, NULL);
     if (rc != GSR_OK) { printf("backward failed: %s\n", gsr_last_error()); return 1; }
     float h_g3[9], h_go[3];
     CK(hipMemcpy(h_g3, g3, 36, hipMemcpyDeviceToHost)); CK(hipMemcpy(h_go, go, 12, hipMemcpyDeviceToHost));

@@ -307,3 +307,31 @@ def test_gradient_arena_matches_separate_buffers():
         assert a.data_ptr() == flat.data_ptr() + 4 * off                   # a view of the bucket, in parameter order
         off += n
     assert off == flat.numel()
+
+
+@pytest.mark.parametrize("deg,max_deg", [(3, 3), (1, 3), (0, 1)])
+def test_fused_raw_parameter_path_matches_activation_graph(deg, max_deg):
+    """render_fused (raw parameters, activations and the SH cat inside the kernels) against
+    render() whose inputs go through torch's exp / sigmoid / normalize / cat and their autograd."""
+    from gaussian_transformer_amd.model import GaussianParams
+    from gaussian_transformer_amd.render import PipelineParams, TorchCamera, render, render_fused
+    sc = synth.make_scene(P=3000, width=128, height=80, sh_degree=deg, s0=0.04, seed=51, max_sh_degree=max_deg, bg=(0.2, 0.1, 0.4))
+    dev = "cuda"
+    cam = TorchCamera(sc.camera, dev)
+    bg = torch.tensor(sc.bg, device=dev)
+    dL = torch.tensor(np.random.default_rng(2).normal(size=(3, 80, 128)).astype(np.float32), device=dev)
+    out = []
+    for fn in (render, render_fused):
+        pc = GaussianParams.from_synthetic(sc, dev)
+        pc._rotation.data *= 1.7                                   # un-normalised quaternions: the normalize Jacobian matters
+        pkg = fn(cam, pc, PipelineParams(), bg, 0.9)
+        (pkg["render"] * dL).sum().backward()
+        out.append((pkg["render"].detach().cpu().numpy(), pkg["radii"].cpu().numpy(), pkg["viewspace_points"].grad.cpu().numpy(),
+                    [p.grad.cpu().numpy() for p in pc.parameters()]))
+    (img0, rad0, v0, g0), (img1, rad1, v1, g1) = out
+    np.testing.assert_array_equal(rad0, rad1)
+    assert_image_close(img1, img0, atol=2e-6, outlier_frac=1e-4, outlier_max=6e-3)
+    assert grad_err(v1, v0) < 1e-4
+    for a, b, name in zip(g1, g0, ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")):
+        assert a.shape == b.shape
+        assert grad_err(a, b) < 2e-4, name

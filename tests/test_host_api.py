@@ -28,7 +28,7 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), name
     assert set(_lib.SIGNATURES) == declared            # the ctypes stub binds exactly the header
-    assert _lib.load().gsr_abi_version() == 1
+    assert _lib.load().gsr_abi_version() == 2
 
 
 def test_drop_in_module_name_and_settings_fields():
