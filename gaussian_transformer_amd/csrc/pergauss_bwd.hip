@@ -10,7 +10,9 @@
 
 namespace gsr {
 
-template <int D>
+// RAW / SPLIT: fused-step extension (raw parameters / split SH tensors) as separate instantiations, so the
+// reference path keeps its register budget.
+template <int D, bool RAW, bool SPLIT>
 __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.P) return;
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
             s[0] = a.scales[3 * si]; s[1] = a.scales[3 * si + 1]; s[2] = a.scales[3 * si + 2];
             const float4 q4 = reinterpret_cast<const float4 *>(a.rotations)[si];
             q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
-            if (a.raw_params) {
+            if (RAW) {
                 s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]);
                 act_normalize4(q, q_inv_norm);
             }
@@ -107,11 +109,11 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
             sh_basis<D>(dir, bas);
             sh_basis_grad<D>(dir, bg3);
             float c[3 * K + 3];
-            if (a.shs_rest) load_sh_row_split<K>(a.shs, a.shs_rest, si, a.M, c);
+            if (SPLIT) load_sh_row_split<K>(a.shs, a.shs_rest, si, a.M, c);
             else load_sh_row<K>(a.shs, si, a.M, c);
             const uint8_t cl = a.clamped[si];
             float ddir[3] = {0.f, 0.f, 0.f};
-            float *out = a.shs_rest ? nullptr : a.dL_dsh + si * (size_t)a.M * 3;
+            float *out = (SPLIT) ? nullptr : a.dL_dsh + si * (size_t)a.M * 3;
             float gch[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) gch[ch] = ((cl >> ch) & 1) ? 0.f : dcol[ch];
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
                 for (int k = 0; k < K; k++)
 #pragma unroll
                     for (int ax = 0; ax < 3; ax++) ddir[ax] += bg3[k][ax] * c[k * 3 + ch] * gch[ch];
-            if (!a.shs_rest) {
+            if (!(SPLIT)) {
 #pragma unroll
                 for (int k = 0; k < K; k++) {
                     out[k * 3 + 0] = bas[k] * gch[0]; out[k * 3 + 1] = bas[k] * gch[1]; out[k * 3 + 2] = bas[k] * gch[2];
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
             drot[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
             drot[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
         }
-        if (a.raw_params) {                            // chain through sigmoid / exp / normalize (scene/gaussian_model.py:33-41)
+        if (RAW) {                   // chain through sigmoid / exp / normalize (scene/gaussian_model.py:33-41)
             const float o = a.rec[GSR_REC_FLOATS * si + 5];
             dop *= o * (1.f - o);
             if (!a.cov3D_precomp) {
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
             }
         }
     } else if (a.shs) {
-        if (!a.shs_rest) {
+        if (!(SPLIT)) {
             float *out = a.dL_dsh + si * (size_t)a.M * 3;
             for (int k = 0; k < 3 * a.M; k++) out[k] = 0.f;
         } else {
@@ -207,12 +209,22 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
 hipError_t launch_pergauss_bwd(const PergaussBwdArgs &a, hipStream_t s) {
     if (a.P <= 0) return hipSuccess;
     const dim3 grid((a.P + 255) / 256), block(256);
-    switch (a.shs ? a.D : 0) {
-        case 0: hipLaunchKernelGGL(pergauss_bwd_kernel<0>, grid, block, 0, s, a); break;
-        case 1: hipLaunchKernelGGL(pergauss_bwd_kernel<1>, grid, block, 0, s, a); break;
-        case 2: hipLaunchKernelGGL(pergauss_bwd_kernel<2>, grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(pergauss_bwd_kernel<3>, grid, block, 0, s, a); break;
+    const int d = a.shs ? a.D : 0;
+    const bool raw = a.raw_params != 0, split = a.shs_rest != nullptr;
+#define GSR_LAUNCH(DD)                                                                                   \
+    do {                                                                                                 \
+        if (!raw && !split) hipLaunchKernelGGL((pergauss_bwd_kernel<DD, false, false>), grid, block, 0, s, a);           \
+        else if (raw && !split) hipLaunchKernelGGL((pergauss_bwd_kernel<DD, true, false>), grid, block, 0, s, a);        \
+        else if (!raw && split) hipLaunchKernelGGL((pergauss_bwd_kernel<DD, false, true>), grid, block, 0, s, a);        \
+        else hipLaunchKernelGGL((pergauss_bwd_kernel<DD, true, true>), grid, block, 0, s, a);                            \
+    } while (0)
+    switch (d) {
+        case 0: GSR_LAUNCH(0); break;
+        case 1: GSR_LAUNCH(1); break;
+        case 2: GSR_LAUNCH(2); break;
+        default: GSR_LAUNCH(3); break;
     }
+#undef GSR_LAUNCH
     return hipGetLastError();
 }
 

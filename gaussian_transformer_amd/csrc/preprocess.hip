@@ -8,7 +8,9 @@
 
 namespace gsr {
 
-template <int D>
+// RAW / SPLIT = the fused-step extension (raw parameters / split SH tensors), separate instantiations so
+// that the reference path keeps its register budget (96 VGPRs, 5 waves/SIMD at D = 3).
+template <int D, bool RAW, bool SPLIT>
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreprocessArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.P) return;
@@ -38,7 +40,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreprocessArgs a) {
             float s[3] = {a.scales[3 * si], a.scales[3 * si + 1], a.scales[3 * si + 2]};
             const float4 q4 = reinterpret_cast<const float4 *>(a.rotations)[si];
             float q[4] = {q4.x, q4.y, q4.z, q4.w};
-            if (a.raw_params) {                       // fused activations: exp / normalize
+            if (RAW) {              // fused activations: exp / normalize
                 s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]);
                 float inv_norm;
                 act_normalize4(q, inv_norm);
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreprocessArgs a) {
             tile_rect(px, py, radius, a.gridx, a.gridy, x0, y0, x1, y1);
             const int area = (x1 - x0) * (y1 - y0);
             if (area != 0) {
-                const float opacity = a.raw_params ? act_sigmoid(a.opacities[si]) : a.opacities[si];
+                const float opacity = (RAW) ? act_sigmoid(a.opacities[si]) : a.opacities[si];
                 float tau = 0.f;
                 int pairs = area;
                 if (a.exact_cull) {                      // count only the tiles the ellipse can reach
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreprocessArgs a) {
                     sh_basis<D>(dir, b);
                     constexpr int K = (D + 1) * (D + 1);
                     float c[3 * K + 3];
-                    if (a.shs_rest) load_sh_row_split<K>(a.shs, a.shs_rest, si, a.M, c);
+                    if (SPLIT) load_sh_row_split<K>(a.shs, a.shs_rest, si, a.M, c);
                     else load_sh_row<K>(a.shs, si, a.M, c);
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
@@ -121,12 +123,22 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreprocessArgs a) {
 hipError_t launch_preprocess_fwd(const PreprocessArgs &a, hipStream_t s) {
     if (a.P <= 0) return hipSuccess;
     const dim3 grid((a.P + 255) / 256), block(256);
-    switch (a.shs ? a.D : 0) {
-        case 0: hipLaunchKernelGGL(preprocess_fwd_kernel<0>, grid, block, 0, s, a); break;
-        case 1: hipLaunchKernelGGL(preprocess_fwd_kernel<1>, grid, block, 0, s, a); break;
-        case 2: hipLaunchKernelGGL(preprocess_fwd_kernel<2>, grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(preprocess_fwd_kernel<3>, grid, block, 0, s, a); break;
+    const int d = a.shs ? a.D : 0;
+    const bool raw = a.raw_params != 0, split = a.shs_rest != nullptr;
+#define GSR_LAUNCH(DD)                                                                                   \
+    do {                                                                                                 \
+        if (!raw && !split) hipLaunchKernelGGL((preprocess_fwd_kernel<DD, false, false>), grid, block, 0, s, a);           \
+        else if (raw && !split) hipLaunchKernelGGL((preprocess_fwd_kernel<DD, true, false>), grid, block, 0, s, a);        \
+        else if (!raw && split) hipLaunchKernelGGL((preprocess_fwd_kernel<DD, false, true>), grid, block, 0, s, a);        \
+        else hipLaunchKernelGGL((preprocess_fwd_kernel<DD, true, true>), grid, block, 0, s, a);                            \
+    } while (0)
+    switch (d) {
+        case 0: GSR_LAUNCH(0); break;
+        case 1: GSR_LAUNCH(1); break;
+        case 2: GSR_LAUNCH(2); break;
+        default: GSR_LAUNCH(3); break;
     }
+#undef GSR_LAUNCH
     return hipGetLastError();
 }
 
