@@ -49,6 +49,8 @@ SIGNATURES = {
     "gsr_l1_ssim_workspace": (_i32, [_i32, _i32, _i32, C.POINTER(_sz)]),
     "gsr_l1_ssim_forward": (_i32, [_p, _i32, _i32, _i32, _p, _p, _f, _p, _p, _sz]),
     "gsr_l1_ssim_backward": (_i32, [_p, _i32, _i32, _i32, _p, _p, _f, _p, _p, _sz, _p]),
+    "gsr_knn_workspace": (_i32, [_i32, C.POINTER(_sz)]),
+    "gsr_knn_mean_dist2": (_i32, [_p, _i32, _p, _p, _p, _sz]),
     "gsr_set_option": (_i32, [C.c_char_p, _i32]),
     "gsr_get_option": (_i32, [C.c_char_p, C.POINTER(_i32)]),
     "gsr_set_profiling": (_i32, [_i32]),

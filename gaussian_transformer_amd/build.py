@@ -31,6 +31,7 @@ SOURCES = {
     "composite_fwd.hip": [],
     "composite_bwd.hip": ["-munsafe-fp-atomics"],
     "ssim_loss.hip": [],
+    "knn.hip": [],
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-result",
           "-fgpu-rdc" if False else "-fno-gpu-rdc"]
@@ -74,6 +75,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "gsr.h"))
     headers.append(os.path.join(HERE, "..", "include", "gsr_loss.h"))
+    headers.append(os.path.join(HERE, "..", "include", "gsr_knn.h"))
     headers.append(os.path.abspath(__file__))
     cc = hipcc()
     jobs = []

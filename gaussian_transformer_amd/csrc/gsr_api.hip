@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "../../include/gsr.h"
+#include "../../include/gsr_knn.h"
 #include "../../include/gsr_loss.h"
 #include "gsr_internal.h"
 
@@ -390,6 +391,22 @@ int32_t gsr_l1_ssim_backward(gsr_stream_t stream, int32_t C, int32_t H, int32_t 
     if (ws_bytes < need) return fail(GSR_ERR_WORKSPACE, "loss workspace %zu < %zu", ws_bytes, need);
     HIP_TRY(launch_l1_ssim_backward(C, H, W, img, gt, lambda_dssim, (const float *)ws, grad_loss, grad_img, (hipStream_t)stream),
             "l1+ssim backward launch");
+    return GSR_OK;
+}
+
+// ---- simple_knn.distCUDA2 equivalent (include/gsr_knn.h) ----
+int32_t gsr_knn_workspace(int32_t N, size_t *bytes) {
+    if (N < 0 || !bytes) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_knn_workspace: bad argument");
+    HIP_TRY(knn_workspace_bytes(N, bytes), "knn temp query");
+    return GSR_OK;
+}
+
+int32_t gsr_knn_mean_dist2(gsr_stream_t stream, int32_t N, const float *points, float *mean_dist2, void *ws, size_t ws_bytes) {
+    if (N < 0 || (N > 0 && (!points || !mean_dist2 || !ws))) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_knn_mean_dist2: bad argument");
+    size_t need = 0;
+    HIP_TRY(knn_workspace_bytes(N, &need), "knn temp query");
+    if (N > 0 && ws_bytes < need) return fail(GSR_ERR_WORKSPACE, "knn workspace %zu < %zu", ws_bytes, need);
+    HIP_TRY(launch_knn(N, points, mean_dist2, ws, (hipStream_t)stream), "knn launch");
     return GSR_OK;
 }
 

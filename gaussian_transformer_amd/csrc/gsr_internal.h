@@ -136,6 +136,9 @@ hipError_t launch_l1_ssim_forward(int C, int H, int W, const float *img, const f
 hipError_t launch_l1_ssim_backward(int C, int H, int W, const float *img, const float *gt, float lambda, const float *dmaps,
                                    const float *grad_loss, float *grad_img, hipStream_t s);
 
+hipError_t knn_workspace_bytes(int N, size_t *bytes);
+hipError_t launch_knn(int N, const float *pts, float *out, void *ws, hipStream_t s);
+
 hipError_t launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s);
 
 }  // namespace gsr
