@@ -120,6 +120,31 @@ def main():
     ps = image_utils.psnr(img1.detach()[None], img2[None])
     np.savez(os.path.join(a.out, "loss.npz"), img1=img1.detach().numpy(), img2=img2.numpy(), l1=l1.item(), ssim=ss.item(),
              loss=loss.item(), grad=img1.grad.numpy(), psnr=ps.numpy())
+    # ---- on-disk formats: bytes cut from the shipped table_ds model + what the reference's loader returns ----
+    import importlib.util, struct, shutil
+    spec = importlib.util.spec_from_file_location("ref_colmap_loader", os.path.join(a.ref, "scene", "colmap_loader.py"))
+    cl = importlib.util.module_from_spec(spec); spec.loader.exec_module(cl)
+    model_dir = os.path.join(a.ref, "table_ds", "sparse", "0")
+    cams = cl.read_intrinsics_binary(os.path.join(model_dir, "cameras.bin"))
+    cam = cams[sorted(cams)[0]]
+    cams2 = cl.read_intrinsics_binary(os.path.join(a.ref, "tiramisu_ds", "sparse", "0", "cameras.bin"))
+    cam2 = cams2[sorted(cams2)[0]]
+    xyz, rgb, err = cl.read_points3D_binary(os.path.join(model_dir, "points3D.bin"))
+    shutil.copyfile(os.path.join(model_dir, "cameras.bin"), os.path.join(a.out, "io_cameras.bin"))
+    K = 64
+    raw = open(os.path.join(model_dir, "points3D.bin"), "rb").read()
+    off = 8
+    for _ in range(K):                      # walk K variable-length records
+        (track,) = struct.unpack_from("<Q", raw, off + 43)
+        off += 43 + 8 + 8 * track
+    open(os.path.join(a.out, "io_points3D_first64.bin"), "wb").write(struct.pack("<Q", K) + raw[8:off])
+    ply = open(os.path.join(model_dir, "points3D.ply"), "rb").read()
+    hend = ply.index(b"end_header\n") + len(b"end_header\n")
+    header = ply[:hend].replace(b"element vertex %d" % xyz.shape[0], b"element vertex %d" % K)
+    open(os.path.join(a.out, "io_points3D_first64.ply"), "wb").write(header + ply[hend:hend + K * 27])
+    np.savez(os.path.join(a.out, "io_colmap.npz"), cam_id=cam.id, cam_model=cam.model, cam_width=cam.width, cam_height=cam.height,
+             cam_params=cam.params, cam2_params=cam2.params, cam2_width=cam2.width, n_points=xyz.shape[0],
+             xyz_first=xyz[:K], rgb_first=rgb[:K], err_first=err[:K], bbox_min=xyz.min(0), bbox_max=xyz.max(0))
     print("wrote", sorted(os.listdir(a.out)))
 
 
