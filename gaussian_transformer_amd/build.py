@@ -28,6 +28,7 @@ SOURCES = {
     "preprocess.hip": ["-ffp-contract=off"],
     "pergauss_bwd.hip": ["-ffp-contract=off"],
     "binning.hip": ["-ffp-contract=off"],     # the tile-row span test must round exactly as in preprocess.hip
+    "depth_order.hip": ["-ffp-contract=off"],
     "composite_fwd.hip": [],
     "composite_bwd.hip": ["-munsafe-fp-atomics"],
     "ssim_loss.hip": [],

@@ -207,6 +207,7 @@ __global__ __launch_bounds__(256) void emit_keys_kernel(int P, int W, int H, int
     }
 }
 
+// P = entries of the depth-ordered list (all Gaussians after the rocPRIM sort, the emitting ones after depth_order.hip)
 hipError_t launch_emit_keys(const GeomView &g, const BinningView &b, int P, int W, int H, int exact_cull, int two_level,
                             hipStream_t s) {
     if (P <= 0) return hipSuccess;

@@ -1,0 +1,385 @@
+// depth_order.hip -- the depth order of the emitting Gaussians and the scan of their pair counts, without
+// a general radix sort.
+//
+// Output (same contract as launch_depth_sort + launch_ordered_scan of binning.hip):
+//   perm[0..Pv)     ids of the Pv Gaussians that emit at least one (tile, Gaussian) pair, ordered by
+//                   (depth bits, id) -- the order a stable sort on depth of id-ordered input gives
+//   offsets[0..Pv)  inclusive scan of tiles[perm[.]]
+//   hdr[DO_PV], hdr[DO_NTOT]  Pv and N (total pairs); hdr[DO_OVERFLOW] != 0 -> nothing usable, the caller
+//                   falls back to the rocPRIM path.
+//
+// rocPRIM's onesweep needs 4 digit passes + histogram + scan + 4 fills (~165 us for 1 M Gaussians, almost all
+// of it launch latency and decoupled-lookback chains over 8 MB of data).  Here: the depth range is cut into
+// nb level-1 buckets (linear in depth, monotone), one counting pass + one scatter pass (workgroup-local LDS
+// histograms; one global atomic per workgroup and touched bucket) place every Gaussian in its bucket in
+// arbitrary order, and one workgroup per bucket finishes the job in LDS:
+// a second, finer counting split (GSR_DO_NSUB sub-buckets) and a rank-by-counting inside each sub-bucket on the
+// full 64-bit (depth bits, id) key, so the result does not depend on arrival order.  A bucket whose keys pile
+// up in one sub-bucket (coplanar splats) is sorted by an in-LDS bitonic network instead: bounded time for any
+// input.  The same workgroup then scans the pair counts of its sorted slice.
+// Every kernel here is latency-bound (8 MB of keys): the design minimises dependent memory round trips and
+// launches -- preprocess leaves per-workgroup depth extrema, so the whole stage is four launches, and the
+// totals the host needs reach it through pinned memory while the last two kernels run.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gsr_internal.h"
+
+namespace gsr {
+
+#define DO_SORT_THREADS 1024
+#define DO_ITEMS (GSR_DO_CAP / DO_SORT_THREADS)   // 8 register-resident items per thread
+#define DO_RANK_MAX 96                            // largest sub-bucket handled by rank-by-counting
+#define DO_CNT_THREADS 1024                       // counting / scatter workgroups: one uint4 (4 Gaussians) per thread per step
+
+DepthOrderPlan depth_order_plan(int P) {
+    DepthOrderPlan p;
+    const long n = P > 0 ? P : 1;
+    p.nb = 64;
+    while (p.nb < GSR_DO_MAXB && (long)p.nb * 2048 < n) p.nb *= 2;
+    p.chunk = 4 * DO_CNT_THREADS;
+    while ((n + p.chunk - 1) / p.chunk > GSR_DO_MAXBLK) p.chunk *= 2;
+    p.nblk = (int)((n + p.chunk - 1) / p.chunk);
+    p.npre = (int)((n + 255) / 256);
+    return p;
+}
+
+__device__ __forceinline__ float do_scale(uint32_t kmin, uint32_t kmax, uint32_t nfine) {
+    const float dmin = __uint_as_float(kmin), dmax = __uint_as_float(kmax);
+    return (kmax > kmin) ? (float)nfine / (dmax - dmin) : 0.f;
+}
+// monotone non-decreasing in the key (positive floats): subtraction, multiplication by a non-negative
+// constant, truncation and the clamp all preserve order
+__device__ __forceinline__ uint32_t do_fine(uint32_t key, float dmin, float scale, uint32_t nfine) {
+    const float v = (__uint_as_float(key) - dmin) * scale;
+    const uint32_t f = v > 0.f ? (uint32_t)v : 0u;
+    return f < nfine ? f : nfine - 1u;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, m));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, m));
+    return v;
+}
+
+// depth range of the emitting Gaussians from the per-workgroup extrema preprocess left (every workgroup
+// reduces the whole list: npre words x 2 out of L2, one round trip)
+__device__ __forceinline__ void do_key_range(int npre, const uint32_t *__restrict__ blkmin, const uint32_t *__restrict__ blkmax,
+                                             uint32_t *s_red /*[2 * 16]*/, uint32_t &kmin, uint32_t &kmax) {
+    uint32_t mn = 0xffffffffu, mx = 0u;
+    for (int j = threadIdx.x; j < npre; j += blockDim.x) { mn = min(mn, blkmin[j]); mx = max(mx, blkmax[j]); }
+    mn = wave_min_u32(mn); mx = wave_max_u32(mx);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_red[w] = mn; s_red[16 + w] = mx; }
+    __syncthreads();
+    mn = 0xffffffffu; mx = 0u;
+    for (int k = 0; k < nw; k++) { mn = min(mn, s_red[k]); mx = max(mx, s_red[16 + k]); }
+    kmin = mn; kmax = mx;
+}
+
+// Level-1 histogram (count, pair-count sum per bucket): LDS per workgroup, then one global atomic per touched
+// bucket.  (A "last workgroup scans the totals" tail needs an agent-scope fence in every workgroup -- an L2
+// write-back per workgroup on this multi-XCD part, 55 us measured -- so the scan is its own one-workgroup launch.)
+__global__ __launch_bounds__(DO_CNT_THREADS) void do_hist_kernel(int P, int chunk, int nb, int npre, const uint32_t *__restrict__ depth,
+                                                                 const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ blkmin,
+                                                                 const uint32_t *__restrict__ blkmax, uint32_t *__restrict__ hdr,
+                                                                 uint32_t *__restrict__ gcnt, uint32_t *__restrict__ gts) {
+    extern __shared__ uint32_t sm[];
+    __shared__ uint32_t s_red[32];
+    uint32_t *h = sm, *ts = sm + nb;
+    for (int b = threadIdx.x; b < 2 * nb; b += DO_CNT_THREADS) sm[b] = 0u;
+    uint32_t kmin, kmax;
+    do_key_range(npre, blkmin, blkmax, s_red, kmin, kmax);          // contains a barrier: sm is zeroed for everyone after it
+    const uint32_t nfine = (uint32_t)nb * GSR_DO_NSUB;
+    const float dmin = __uint_as_float(kmin), scale = do_scale(kmin, kmax, nfine);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[DO_KMIN] = kmin; hdr[DO_KMAX] = kmax; }
+    const int i0 = blockIdx.x * chunk, i1 = min(P, i0 + chunk);
+    for (int i = i0 + 4 * (int)threadIdx.x; i < i1; i += 4 * DO_CNT_THREADS) {
+        const uint4 t4 = *reinterpret_cast<const uint4 *>(tiles + i);   // padded allocations: the tail read stays inside
+        const uint4 d4 = *reinterpret_cast<const uint4 *>(depth + i);
+        const uint32_t tt[4] = {t4.x, t4.y, t4.z, t4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (i + q < i1 && tt[q] > 0u) {
+                const uint32_t b = do_fine(dd[q], dmin, scale, nfine) / GSR_DO_NSUB;
+                atomicAdd(&h[b], 1u);
+                atomicAdd(&ts[b], tt[q]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += DO_CNT_THREADS) {
+        const uint32_t c = h[b];
+        if (c) { atomicAdd(&gcnt[b], c); atomicAdd(&gts[b], ts[b]); }
+    }
+}
+
+// one workgroup: bucket starts, pair-count bases, Pv, N, overflow flag; the totals also go straight to the
+// caller's pinned host words (host_out may be NULL), sequence number last
+__global__ __launch_bounds__(DO_CNT_THREADS) void do_bucket_scan_kernel(int nb, const uint32_t *__restrict__ gcnt,
+                                                                        const uint32_t *__restrict__ gts, uint32_t *__restrict__ bstart,
+                                                                        uint32_t *__restrict__ tbase, uint32_t *__restrict__ hdr,
+                                                                        uint32_t *host_out, uint32_t seq) {
+    __shared__ uint32_t wtot[2][16];
+    __shared__ uint32_t s_over;
+    if (threadIdx.x == 0) s_over = 0u;
+    __syncthreads();
+    // thread t owns buckets 2t, 2t+1 (nb <= GSR_DO_MAXB = 2 * DO_CNT_THREADS)
+    const int b0 = 2 * (int)threadIdx.x;
+    uint32_t c0 = 0, c1 = 0, t0 = 0, t1 = 0;
+    if (b0 < nb) { c0 = gcnt[b0]; t0 = gts[b0]; c1 = gcnt[b0 + 1]; t1 = gts[b0 + 1]; }
+    const uint32_t sumc = c0 + c1, sumt = t0 + t1;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t ic = wave_incl_scan_u32(sumc, lane), it = wave_incl_scan_u32(sumt, lane);
+    if (lane == 63) { wtot[0][w] = ic; wtot[1][w] = it; }
+    if (c0 > GSR_DO_CAP || c1 > GSR_DO_CAP) atomicOr(&s_over, 1u);
+    __syncthreads();
+    uint32_t ec = ic - sumc, et = it - sumt;
+    for (int k = 0; k < w; k++) { ec += wtot[0][k]; et += wtot[1][k]; }
+    if (b0 < nb) {
+        bstart[b0] = ec; tbase[b0] = et;
+        bstart[b0 + 1] = ec + c0; tbase[b0 + 1] = et + t0;
+    }
+    if (threadIdx.x == DO_CNT_THREADS - 1) {                       // owns nothing or the last pair: ec + sumc is the total
+        const uint32_t pv = ec + sumc, ntot = et + sumt, over = s_over;
+        bstart[nb] = pv; tbase[nb] = ntot;
+        hdr[DO_PV] = pv; hdr[DO_NTOT] = ntot; hdr[DO_OVERFLOW] = over;
+        if (host_out) {
+            host_out[0] = over; host_out[1] = pv; host_out[2] = ntot;
+            __threadfence_system();
+            __hip_atomic_store(&host_out[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// place every emitting Gaussian in its level-1 bucket: the workgroup reserves one run per touched bucket
+// (returning global atomic), arrival order inside the bucket is arbitrary
+__global__ __launch_bounds__(DO_CNT_THREADS) void do_scatter_kernel(int P, int chunk, int nb, const uint32_t *__restrict__ depth,
+                                                                    const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ hdr,
+                                                                    const uint32_t *__restrict__ bstart, uint32_t *__restrict__ gcur,
+                                                                    uint64_t *__restrict__ comp) {
+    extern __shared__ uint32_t h[];                                // counts, then run bases
+    if (hdr[DO_OVERFLOW]) return;                                  // grid-uniform: the host takes the rocPRIM path
+    for (int b = threadIdx.x; b < nb; b += DO_CNT_THREADS) h[b] = 0u;
+    __syncthreads();
+    const uint32_t kmin = hdr[DO_KMIN], kmax = hdr[DO_KMAX], nfine = (uint32_t)nb * GSR_DO_NSUB;
+    const float dmin = __uint_as_float(kmin), scale = do_scale(kmin, kmax, nfine);
+    const int i0 = blockIdx.x * chunk, i1 = min(P, i0 + chunk);
+    const int steps = chunk / (4 * DO_CNT_THREADS);                // 1 unless P > 2 M
+    for (int st = 0; st < steps; st++) {
+        // one pass per step keeps the per-thread state at 4 items; runs reserved by different steps are independent
+        const int i = i0 + st * 4 * DO_CNT_THREADS + 4 * (int)threadIdx.x;
+        uint32_t key[4] = {0u, 0u, 0u, 0u}, br[4] = {~0u, ~0u, ~0u, ~0u};
+        if (i < i1) {
+            const uint4 t4 = *reinterpret_cast<const uint4 *>(tiles + i);
+            const uint4 d4 = *reinterpret_cast<const uint4 *>(depth + i);
+            const uint32_t tt[4] = {t4.x, t4.y, t4.z, t4.w};
+            key[0] = d4.x; key[1] = d4.y; key[2] = d4.z; key[3] = d4.w;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (i + q < i1 && tt[q] > 0u) {
+                    const uint32_t b = do_fine(key[q], dmin, scale, nfine) / GSR_DO_NSUB;
+                    br[q] = b | (atomicAdd(&h[b], 1u) << 12);      // bucket (< 4096) | arrival rank in this step (<= 4096)
+                }
+            }
+        }
+        __syncthreads();
+        for (int b = threadIdx.x; b < nb; b += DO_CNT_THREADS) {
+            const uint32_t c = h[b];
+            h[b] = c ? bstart[b] + atomicAdd(&gcur[b], c) : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (br[q] != ~0u) comp[h[br[q] & 0xfffu] + (br[q] >> 12)] = ((uint64_t)key[q] << 32) | (uint32_t)(i + q);
+        __syncthreads();
+        if (st + 1 < steps) {
+            for (int b = threadIdx.x; b < nb; b += DO_CNT_THREADS) h[b] = 0u;
+            __syncthreads();
+        }
+    }
+}
+
+// one workgroup per level-1 bucket: order its keys in LDS, then scan the pair counts of the ordered slice
+__global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, const uint32_t *__restrict__ hdr,
+                                                                        const uint32_t *__restrict__ bstart,
+                                                                        const uint32_t *__restrict__ tbase,
+                                                                        const uint64_t *__restrict__ comp,
+                                                                        const uint32_t *__restrict__ tiles,
+                                                                        uint32_t *__restrict__ perm, uint32_t *__restrict__ offsets) {
+    extern __shared__ uint64_t buf[];                              // [GSR_DO_CAP]
+    __shared__ uint32_t start[GSR_DO_NSUB + 1];
+    __shared__ uint32_t wsum[DO_SORT_THREADS / 64];
+    __shared__ uint32_t s_max;
+    if (hdr[DO_OVERFLOW]) return;                                  // grid-uniform
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t s0 = bstart[b];
+    const int n = (int)(bstart[b + 1] - s0);
+    if (n == 0) return;                                            // workgroup-uniform
+    const uint32_t kmin = hdr[DO_KMIN], kmax = hdr[DO_KMAX], nfine = (uint32_t)nb * GSR_DO_NSUB;
+    const float dmin = __uint_as_float(kmin), scale = do_scale(kmin, kmax, nfine);
+    if (tid <= GSR_DO_NSUB) start[tid] = 0u;
+    if (tid == 0) s_max = 0u;
+    __syncthreads();
+    // ---- sub-bucket histogram; the items stay in registers until they are placed ----
+    {
+        uint64_t c[DO_ITEMS];
+        uint32_t sr[DO_ITEMS];                                     // sub-bucket | arrival rank << 16
+#pragma unroll
+        for (int q = 0; q < DO_ITEMS; q++) {
+            const int j = tid + q * DO_SORT_THREADS;
+            c[q] = 0ull; sr[q] = 0u;
+            if (j < n) c[q] = comp[s0 + j];
+        }
+#pragma unroll
+        for (int q = 0; q < DO_ITEMS; q++) {
+            const int j = tid + q * DO_SORT_THREADS;
+            if (j < n) {
+                const uint32_t sub = do_fine((uint32_t)(c[q] >> 32), dmin, scale, nfine) & (GSR_DO_NSUB - 1);
+                sr[q] = sub | (atomicAdd(&start[sub], 1u) << 16);
+            }
+        }
+        __syncthreads();
+        {   // exclusive scan of the sub-bucket counts (thread t < 512 owns sub-bucket t) + their maximum
+            const uint32_t v = tid < GSR_DO_NSUB ? start[tid] : 0u;
+            const uint32_t mx = wave_max_u32(v);
+            const uint32_t incl = wave_incl_scan_u32(v, lane);
+            if (lane == 63) { wsum[w] = incl; atomicMax(&s_max, mx); }
+            __syncthreads();
+            uint32_t ex = incl - v;
+            for (int k = 0; k < w; k++) ex += wsum[k];
+            if (tid < GSR_DO_NSUB) start[tid] = ex;
+            if (tid == GSR_DO_NSUB) start[GSR_DO_NSUB] = (uint32_t)n;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < DO_ITEMS; q++) {
+            const int j = tid + q * DO_SORT_THREADS;
+            if (j < n) buf[start[sr[q] & 0xffffu] + (sr[q] >> 16)] = c[q];
+        }
+    }
+    __syncthreads();
+    uint32_t *sid = reinterpret_cast<uint32_t *>(buf);             // sorted ids, aliasing buf once it has been consumed
+    if (s_max <= DO_RANK_MAX) {                                    // workgroup-uniform
+        // the items are grouped by sub-bucket now: thread takes the item at position j, counts the smaller
+        // keys of its sub-bucket
+        uint32_t rk[DO_ITEMS], id[DO_ITEMS];
+#pragma unroll
+        for (int q = 0; q < DO_ITEMS; q++) {
+            const int j = tid + q * DO_SORT_THREADS;
+            rk[q] = 0u; id[q] = 0u;
+            if (j < n) {
+                const uint64_t me = buf[j];
+                const uint32_t sub = do_fine((uint32_t)(me >> 32), dmin, scale, nfine) & (GSR_DO_NSUB - 1);
+                const uint32_t a0 = start[sub], a1 = start[sub + 1];
+                uint32_t r = a0;
+                for (uint32_t k = a0; k < a1; k++) r += buf[k] < me ? 1u : 0u;
+                rk[q] = r; id[q] = (uint32_t)me;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < DO_ITEMS; q++) {
+            const int j = tid + q * DO_SORT_THREADS;
+            if (j < n) sid[rk[q]] = id[q];
+        }
+    } else {                                                       // degenerate depth distribution: bitonic network
+        int m = 64;
+        while (m < n) m <<= 1;
+        for (int j = n + tid; j < m; j += DO_SORT_THREADS) buf[j] = ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= m; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (m >> 1); t += DO_SORT_THREADS) {
+                    const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int hi = lo + j;
+                    const uint64_t x = buf[lo], y = buf[hi];
+                    const bool up = (lo & k) == 0;
+                    if ((x > y) == up) { buf[lo] = y; buf[hi] = x; }
+                }
+                __syncthreads();
+            }
+        }
+        uint32_t id[DO_ITEMS];
+#pragma unroll
+        for (int q = 0; q < DO_ITEMS; q++) {
+            const int j = tid + q * DO_SORT_THREADS;
+            id[q] = j < n ? (uint32_t)buf[j] : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < DO_ITEMS; q++) {
+            const int j = tid + q * DO_SORT_THREADS;
+            if (j < n) sid[j] = id[q];
+        }
+    }
+    __syncthreads();
+    // ---- scan of the pair counts in sorted order: thread tid owns positions [tid*k, tid*k + k) ----
+    const int k = (n + DO_SORT_THREADS - 1) / DO_SORT_THREADS;     // <= DO_ITEMS
+    uint32_t ids[DO_ITEMS], tt[DO_ITEMS];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int q = 0; q < DO_ITEMS; q++) {
+        const int j = tid * k + q;
+        ids[q] = 0u; tt[q] = 0u;
+        if (q < k && j < n) { ids[q] = sid[j]; tt[q] = tiles[ids[q]]; }
+    }
+#pragma unroll
+    for (int q = 0; q < DO_ITEMS; q++) sum += tt[q];
+    const uint32_t incl = wave_incl_scan_u32(sum, lane);
+    __syncthreads();                                               // wsum is reused
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t run = tbase[b] + incl - sum;
+    for (int kk = 0; kk < w; kk++) run += wsum[kk];
+#pragma unroll
+    for (int q = 0; q < DO_ITEMS; q++) {
+        const int j = tid * k + q;
+        if (q < k && j < n) {
+            run += tt[q];
+            perm[s0 + j] = ids[q];
+            offsets[s0 + j] = run;
+        }
+    }
+}
+
+hipError_t launch_depth_order_count(const GeomView &g, int P, uint32_t *host_out, uint32_t seq, hipStream_t s) {
+    const DepthOrderPlan pl = depth_order_plan(P);
+    const DepthOrderView &d = g.dord;
+    hipLaunchKernelGGL(do_hist_kernel, dim3(pl.nblk), dim3(DO_CNT_THREADS), 2 * pl.nb * sizeof(uint32_t), s, P, pl.chunk, pl.nb, pl.npre,
+                       reinterpret_cast<const uint32_t *>(g.depth), g.tiles, d.blkmin, d.blkmax, d.hdr, d.gcnt, d.gts);
+    hipLaunchKernelGGL(do_bucket_scan_kernel, dim3(1), dim3(DO_CNT_THREADS), 0, s, pl.nb, d.gcnt, d.gts, d.bstart, d.tbase, d.hdr, host_out, seq);
+    return hipGetLastError();
+}
+
+hipError_t launch_depth_order_place(const GeomView &g, int P, hipStream_t s) {
+    const DepthOrderPlan pl = depth_order_plan(P);
+    const DepthOrderView &d = g.dord;
+    static bool attr_set = false;   // benign race: the attribute is idempotent
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(do_local_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           GSR_DO_CAP * (int)sizeof(uint64_t));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(do_scatter_kernel, dim3(pl.nblk), dim3(DO_CNT_THREADS), pl.nb * sizeof(uint32_t), s, P, pl.chunk, pl.nb,
+                       reinterpret_cast<const uint32_t *>(g.depth), g.tiles, d.hdr, d.bstart, d.gcur, d.comp);
+    hipLaunchKernelGGL(do_local_sort_kernel, dim3(pl.nb), dim3(DO_SORT_THREADS), GSR_DO_CAP * sizeof(uint64_t), s, pl.nb, d.hdr, d.bstart,
+                       d.tbase, d.comp, g.tiles, g.perm, g.offsets);
+    return hipGetLastError();
+}
+
+}  // namespace gsr

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 
 #include "../../include/gsr.h"
 #include "../../include/gsr_knn.h"
@@ -23,6 +24,8 @@ static std::atomic<int> g_bwd_npx{2};
 static std::atomic<int> g_fwd_npx{2};
 static std::atomic<int> g_wpb{1};           // waves per workgroup of the compositing kernels (waves are independent)
 static std::atomic<int> g_two_level_sort{1};   // 1: rocPRIM by tile + per-tile LDS depth sort; 0: one global 64-bit-key sort      // same for the forward compositing kernel      // 8x8 pixel blocks per wave in the reverse compositing kernel (1, 2 or 4)   // output-invariant exact splat-vs-tile culling (gsr_set_option)
+static std::atomic<int> g_depth_buckets{1};    // 0: rocPRIM radix sort + scan; 1: depth_order.hip when P is large enough; 2: always (tests)
+#define GSR_DEPTH_BUCKETS_MIN_P 32768          // below this rocPRIM's single-workgroup sort is as fast
 static float g_stage_ms[GSR_NUM_STAGES] = {0};
 static const char *const k_stage_names[GSR_NUM_STAGES] = {
     "fwd.preprocess", "fwd.depth_order+scan", "fwd.readback_N", "fwd.emit_keys", "fwd.sort", "fwd.ranges", "(unused)",
@@ -59,6 +62,14 @@ GeomView carve_geom(void *base, int P, size_t scan_tb, size_t dsort_tb) {
     g.scan_temp_bytes = scan_tb;
     g.dsort_temp = take(dsort_tb);
     g.dsort_temp_bytes = dsort_tb;
+    const DepthOrderPlan pl = depth_order_plan(P);
+    g.dord.hdr = (uint32_t *)take(GSR_DO_ZERO_WORDS * sizeof(uint32_t));
+    g.dord.gcnt = g.dord.hdr + DO_HDR_WORDS; g.dord.gts = g.dord.gcnt + GSR_DO_MAXB; g.dord.gcur = g.dord.gts + GSR_DO_MAXB;
+    g.dord.bstart = (uint32_t *)take((pl.nb + 1) * sizeof(uint32_t));
+    g.dord.tbase = (uint32_t *)take((pl.nb + 1) * sizeof(uint32_t));
+    g.dord.blkmin = (uint32_t *)take(pl.npre * sizeof(uint32_t));
+    g.dord.blkmax = (uint32_t *)take(pl.npre * sizeof(uint32_t));
+    g.dord.comp = (uint64_t *)take(n * sizeof(uint64_t));
     g.total_bytes = off;
     return g;
 }
@@ -108,6 +119,46 @@ static hipError_t any_sort_temp_bytes(int64_t N, int W, int H, size_t *bytes) {
     return e;
 }
 
+// Four pinned host words per in-flight forward call: the bucket-scan kernel stores {overflow, Pv, N, seq}
+// into them and the host polls `seq`, so nothing (copy engine, barrier packet) sits between the kernels that
+// produce the totals and the kernels queued behind them while the host catches up.
+struct ReadbackSlot {
+    std::atomic<int> busy{0};
+    uint32_t *host = nullptr;     // 4 pinned, device-visible words
+    int device = -1;
+};
+static ReadbackSlot g_slots[8];
+static std::atomic<uint32_t> g_seq{1};
+static ReadbackSlot *acquire_slot() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    for (auto &sl : g_slots) {
+        int expect = 0;
+        if (!sl.busy.compare_exchange_strong(expect, 1)) continue;
+        if (sl.host && sl.device != dev) { sl.busy.store(0); continue; }
+        if (!sl.host) {
+            if (hipHostMalloc((void **)&sl.host, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { sl.host = nullptr; sl.busy.store(0); return nullptr; }
+            sl.device = dev;
+        }
+        return &sl;
+    }
+    return nullptr;
+}
+static void release_slot(ReadbackSlot *sl) { if (sl) sl->busy.store(0); }
+// spin on the sequence word; gives up after ~2 s (the caller then synchronises the stream instead and the slot
+// is retired: its kernel may still write to it)
+static bool wait_seq(const ReadbackSlot *sl, uint32_t seq) {
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint32_t spin = 1;; spin++) {
+        if (__atomic_load_n(&sl->host[3], __ATOMIC_ACQUIRE) == seq) return true;
+        if ((spin & 0xfffffu) == 0) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if (t1.tv_sec - t0.tv_sec > 2) return false;
+        }
+    }
+}
+
 struct StageTimer {   // hipEvent pairs on the caller's stream; active only under gsr_set_profiling(1)
     hipStream_t s;
     bool on;
@@ -150,6 +201,10 @@ const char *gsr_last_error(void) { return g_err; }
 int32_t gsr_set_option(const char *name, int32_t value) {
     if (name && !strcmp(name, "exact_tile_cull")) { g_exact_cull.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "two_level_sort")) { g_two_level_sort.store(value ? 1 : 0); return GSR_OK; }
+    if (name && !strcmp(name, "depth_buckets")) {
+        if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARGUMENT, "depth_buckets must be 0, 1 or 2");
+        g_depth_buckets.store(value); return GSR_OK;
+    }
     if (name && !strcmp(name, "composite_waves_per_block")) {
         if (value != 1 && value != 2 && value != 4) return fail(GSR_ERR_INVALID_ARGUMENT, "composite_waves_per_block must be 1, 2 or 4");
         g_wpb.store(value); return GSR_OK;
@@ -169,6 +224,7 @@ int32_t gsr_get_option(const char *name, int32_t *value) {
     if (name && value && !strcmp(name, "bwd_blocks_per_wave")) { *value = g_bwd_npx.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "fwd_blocks_per_wave")) { *value = g_fwd_npx.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "two_level_sort")) { *value = g_two_level_sort.load(); return GSR_OK; }
+    if (name && value && !strcmp(name, "depth_buckets")) { *value = g_depth_buckets.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "composite_waves_per_block")) { *value = g_wpb.load(); return GSR_OK; }
     return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_get_option: unknown option '%s'", name ? name : "(null)");
 }
@@ -254,13 +310,38 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     HIP_TRY(launch_preprocess_fwd(pa, s), "preprocess launch");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "preprocess");
     tm.mark(1);
-    HIP_TRY(launch_depth_sort(g, P, s), "depth sort");
-    HIP_TRY(launch_ordered_scan(g, P, s), "ordered scan");
-    if (debug) HIP_TRY(hipStreamSynchronize(s), "depth order + scan");
-    tm.mark(2);
     uint32_t n32 = 0;
-    HIP_TRY(hipMemcpyAsync(&n32, g.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read N");
-    HIP_TRY(hipStreamSynchronize(s), "read N sync");
+    int P_list = P;                                   // entries of the depth-ordered list (perm / offsets)
+    const int dbopt = g_depth_buckets.load();
+    bool bucketed = dbopt == 2 || (dbopt == 1 && P >= GSR_DEPTH_BUCKETS_MIN_P);
+    if (bucketed) {
+        uint32_t h[3] = {1u, 0u, 0u};
+        ReadbackSlot *sl = debug ? nullptr : acquire_slot();
+        const uint32_t seq = sl ? (g_seq.fetch_add(1) | 0x80000000u) : 0u;
+        if (sl) sl->host[3] = 0u;
+        hipError_t e = launch_depth_order_count(g, P, sl ? sl->host : nullptr, seq, s);
+        if (e == hipSuccess) e = launch_depth_order_place(g, P, s);        // runs while the host waits for the totals
+        if (e != hipSuccess) { release_slot(sl); return fail(GSR_ERR_HIP, "depth order: %s (%d)", hipGetErrorString(e), (int)e); }
+        if (debug) HIP_TRY(hipStreamSynchronize(s), "depth order");
+        tm.mark(2);
+        if (sl && wait_seq(sl, seq)) {
+            h[0] = sl->host[0]; h[1] = sl->host[1]; h[2] = sl->host[2];
+            release_slot(sl);
+        } else {                                      // no slot, debug mode, or the poll timed out (slot stays retired)
+            HIP_TRY(hipMemcpyAsync(h, g.dord.hdr + DO_OVERFLOW, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read N");
+            HIP_TRY(hipStreamSynchronize(s), "read N sync");
+        }
+        if (h[0]) bucketed = false;                   // a bucket exceeds the LDS capacity: general sort below
+        else { P_list = (int)h[1]; n32 = h[2]; }
+    }
+    if (!bucketed) {
+        HIP_TRY(launch_depth_sort(g, P, s), "depth sort");
+        HIP_TRY(launch_ordered_scan(g, P, s), "ordered scan");
+        if (debug) HIP_TRY(hipStreamSynchronize(s), "depth order + scan");
+        tm.mark(2);
+        HIP_TRY(hipMemcpyAsync(&n32, g.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read N");
+        HIP_TRY(hipStreamSynchronize(s), "read N sync");
+    }
     const int64_t N = (int64_t)n32;
     if (num_rendered) *num_rendered = N;
 
@@ -274,7 +355,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     b = carve_binning(bin_ptr, N, sort_tb);
     tm.mark(3);
     if (N > 0) {
-        HIP_TRY(launch_emit_keys(g, b, P, W, H, pa.exact_cull, two_level, s), "emit keys launch");
+        HIP_TRY(launch_emit_keys(g, b, P_list, W, H, pa.exact_cull, two_level, s), "emit keys launch");
         if (debug) HIP_TRY(hipStreamSynchronize(s), "emit keys");
         tm.mark(4);
         if (two_level) HIP_TRY(launch_sort2_by_tile(b, N, tile_bits(W, H) > 0 ? tile_bits(W, H) : 1, s), "radix sort by tile");

@@ -20,6 +20,23 @@ static inline int ceil_log2_u32(uint32_t x) { int b = 0; while ((1u << b) < x &&
 //   [0..2] dL/drgb  [3..4] sum s*(conic d) (= dL/dmean2D / -(W/2,H/2))  [5..7] sum s*d d^T (= dL/dconic / -0.5)  [8] dL/dopacity
 #define GSR_ACC_FLOATS 16
 
+// ---- depth_order.hip: bucketed depth order (replaces the rocPRIM depth sort + ordered scan) ----
+#define GSR_DO_CAP 8192      // largest level-1 bucket one workgroup orders in LDS (64 KB of 64-bit keys)
+#define GSR_DO_NSUB 512      // level-2 sub-buckets per bucket
+#define GSR_DO_MAXB 2048     // level-1 buckets, at most
+#define GSR_DO_MAXBLK 512    // counting / scatter workgroups, at most
+enum { DO_KMIN = 0, DO_KMAX = 1, DO_DONE = 2, DO_OVERFLOW = 3, DO_PV = 4, DO_NTOT = 5, DO_HDR_WORDS = 16 };
+#define GSR_DO_ZERO_WORDS (DO_HDR_WORDS + 3 * GSR_DO_MAXB)   // hdr | gcnt | gts | gcur, contiguous, zeroed by preprocess
+struct DepthOrderPlan { int nb, nblk, chunk, npre; };
+DepthOrderPlan depth_order_plan(int P);
+struct DepthOrderView {
+    uint32_t *hdr;           // [DO_HDR_WORDS]; [DO_OVERFLOW, DO_PV, DO_NTOT] are read back by the host
+    uint32_t *gcnt, *gts, *gcur; // [GSR_DO_MAXB] bucket sizes, pair-count sums, scatter cursors
+    uint32_t *bstart, *tbase;    // [nb + 1] first position / pair-count base of every bucket
+    uint32_t *blkmin, *blkmax;   // [npre] depth-bit extrema of the emitting Gaussians of every preprocess workgroup
+    uint64_t *comp;              // [P] (depth bits << 32 | id), grouped by bucket
+};
+
 struct GeomView {          // per-Gaussian state, P entries each
     float *rec;            // [P][12]
     float *depth;          // [P]
@@ -33,6 +50,7 @@ struct GeomView {          // per-Gaussian state, P entries each
     size_t scan_temp_bytes;
     void *dsort_temp;
     size_t dsort_temp_bytes;
+    DepthOrderView dord;
     size_t total_bytes;
 };
 GeomView carve_geom(void *base, int P, size_t scan_temp_bytes, size_t dsort_temp_bytes);
@@ -82,6 +100,9 @@ hipError_t launch_scan(const GeomView &g, int P, hipStream_t s);
 
 hipError_t sort_temp_bytes(int64_t N, int bits, size_t *bytes);
 hipError_t launch_emit_keys(const GeomView &g, const BinningView &b, int P, int W, int H, int exact_cull, int two_level, hipStream_t s);
+// histogram + bucket scan -> hdr totals; host_out (pinned, may be NULL) receives {overflow, Pv, N, seq}
+hipError_t launch_depth_order_count(const GeomView &g, int P, uint32_t *host_out, uint32_t seq, hipStream_t s);
+hipError_t launch_depth_order_place(const GeomView &g, int P, hipStream_t s);   // scatter, per-bucket order + scan -> perm, offsets
 hipError_t sort2_temp_bytes(int64_t N, int tile_bits, size_t *bytes);
 hipError_t launch_sort2_by_tile(const BinningView &b, int64_t N, int tile_bits, hipStream_t s);
 hipError_t depth_sort_temp_bytes(int P, size_t *bytes);

@@ -11,10 +11,13 @@ namespace gsr {
 // RAW / SPLIT = the fused-step extension (raw parameters / split SH tensors), separate instantiations so
 // that the reference path keeps its register budget (96 VGPRs, 5 waves/SIMD at D = 3).
 template <int D, bool RAW, bool SPLIT>
-__global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreprocessArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void preprocess_fwd_kernel(PreprocessArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.P) return;
-    const size_t si = (size_t)i;
+    for (int j = i; j < GSR_DO_ZERO_WORDS; j += gridDim.x * 256) a.g.dord.hdr[j] = 0u;    // counters of depth_order.hip
+    // no early exit: the workgroup reduces the depth extrema of its emitting Gaussians at the end.  Lanes past
+    // the end recompute Gaussian P-1 and store nothing.
+    const bool live = i < a.P;
+    const size_t si = (size_t)(live ? i : a.P - 1);
 
     // defaults for a culled Gaussian
     int radius_out = 0;
@@ -111,13 +114,27 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreprocessArgs a) {
             }
         }
     }
-    float4 *rec = reinterpret_cast<float4 *>(a.g.rec) + 3 * si;
-    rec[0] = r0; rec[1] = r1; rec[2] = r2;
-    a.g.depth[si] = depth_out;
-    a.g.rect[si] = rect_out;
-    a.g.tiles[si] = tiles_out;
-    a.g.clamped[si] = clamp_out;
-    a.radii[si] = radius_out;
+    if (live) {
+        float4 *rec = reinterpret_cast<float4 *>(a.g.rec) + 3 * si;
+        rec[0] = r0; rec[1] = r1; rec[2] = r2;
+        a.g.depth[si] = depth_out;
+        a.g.rect[si] = rect_out;
+        a.g.tiles[si] = tiles_out;
+        a.g.clamped[si] = clamp_out;
+        a.radii[si] = radius_out;
+    }
+    // depth-bit extrema of this workgroup's emitting Gaussians (depth_order.hip derives its bucket map from them)
+    __shared__ uint32_t s_mn[4], s_mx[4];
+    const bool emits = live && tiles_out > 0u;
+    uint32_t mn = emits ? __float_as_uint(depth_out) : 0xffffffffu, mx = emits ? __float_as_uint(depth_out) : 0u;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, m)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, m)); }
+    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.g.dord.blkmin[blockIdx.x] = min(min(s_mn[0], s_mn[1]), min(s_mn[2], s_mn[3]));
+        a.g.dord.blkmax[blockIdx.x] = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
+    }
 }
 
 hipError_t launch_preprocess_fwd(const PreprocessArgs &a, hipStream_t s) {

@@ -130,9 +130,12 @@ int32_t gsr_debug_read_image_state(gsr_stream_t stream, int32_t W, int32_t H, co
  *        {alpha >= 1/255} can reach a pixel of the tile, instead of every tile of upstream's
  *        3-sigma bounding square.  Output-invariant (dropped pairs are skipped by every pixel's
  *        alpha test anyway); num_rendered and the internal lists shrink.  0 = upstream's rule.
- *   "two_level_sort" (default 1): order the pairs with a stable rocPRIM radix sort on the TILE id only
- *        and finish each tile's slice with an in-LDS sort on (depth bits, Gaussian id); identical
- *        resulting order to 0 = one global radix sort on tile<<32|depth.  Speed only.
+ *   "two_level_sort" (default 1): put the Gaussians in (depth bits, id) order first, emit the pairs in that
+ *        order and finish with a STABLE radix sort on the tile id only; identical resulting order to
+ *        0 = one global radix sort on tile<<32|depth.  Speed only.
+ *   "depth_buckets" (0, 1 or 2; default 1): how the Gaussians are put in depth order.  0 = rocPRIM radix sort
+ *        + scan; 1 = the bucketed depth order of csrc/depth_order.hip when P >= 32768 (falls back to 0 by itself
+ *        when a depth bucket does not fit in LDS); 2 = bucketed for every P (tests).  Same order.  Speed only.
  *   "composite_waves_per_block" (1, 2 or 4; default 1): wave64s per workgroup of the compositing
  *        kernels.  The waves never synchronise, so 1 lets every wave retire (and be replaced) alone.
  *   "fwd_blocks_per_wave", "bwd_blocks_per_wave" (1, 2 or 4; default 2): 8x8 pixel blocks one

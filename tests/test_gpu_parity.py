@@ -70,8 +70,32 @@ def test_stages_bit_exact_against_oracle(kw, two_level, upstream_tile_rule):
         _lib.set_option("two_level_sort", 1)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(P=3000, width=160, height=112, sh_degree=3, s0=0.03, seed=0),
+    dict(P=1500, width=100, height=57, sh_degree=1, s0=0.06, seed=1, zmin=0.05, zmax=5.0),   # culled splats
+    dict(P=20000, width=32, height=32, sh_degree=0, s0=0.8, seed=5),
+    dict(P=100000, width=320, height=200, sh_degree=0, s0=0.01, seed=6),                     # 25 counting workgroups
+    dict(P=6000, width=160, height=112, sh_degree=0, s0=0.03, seed=7, zmin=4.0, zmax=4.0),   # one depth: bitonic path
+    dict(P=20000, width=160, height=112, sh_degree=0, s0=0.02, seed=8, zmin=4.0, zmax=4.0),  # bucket > LDS: rocPRIM fallback
+    dict(P=30000, width=160, height=112, sh_degree=0, s0=0.02, seed=9, quantize_z=0.5),      # 17 depths: ties in every bucket
+    dict(P=30000, width=160, height=112, sh_degree=0, s0=0.02, seed=10, quantize_z=0.001),   # small tie groups: rank path
+])
+def test_bucketed_depth_order_bit_exact(kw, upstream_tile_rule):
+    """depth_order.hip forced on (it is automatic only for P >= 32768): same sorted pair list as the oracle's one
+    stable sort, including exact depth ties (ascending Gaussian id) and degenerate depth distributions."""
+    from gaussian_transformer_amd import _lib
+    _lib.set_option("depth_buckets", 2)
+    try:
+        _check_stages_bit_exact(dict(kw), 1)
+    finally:
+        _lib.set_option("depth_buckets", 1)
+
+
 def _check_stages_bit_exact(kw, two_level):
+    qz = kw.pop("quantize_z", None) if "quantize_z" in kw else None
     sc = synth.make_scene(**kw)
+    if qz:
+        sc.means3D[:, 2] = np.round(sc.means3D[:, 2] / qz) * qz
     S = oracle_scene(sc, scale_modifier=1.0)
     f = ref.get("f32").forward(S)
     og, ob, oi = f["state"].geom(), f["state"].binning(), f["state"].image_state()
