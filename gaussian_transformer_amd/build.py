@@ -29,6 +29,7 @@ SOURCES = {
     "pergauss_bwd.hip": ["-ffp-contract=off"],
     "binning.hip": ["-ffp-contract=off"],     # the tile-row span test must round exactly as in preprocess.hip
     "depth_order.hip": ["-ffp-contract=off"],
+    "tile_lists.hip": ["-ffp-contract=off"],      # same tile-row spans as preprocess.hip, bit for bit
     "composite_fwd.hip": [],
     "composite_bwd.hip": ["-munsafe-fp-atomics"],
     "ssim_loss.hip": [],

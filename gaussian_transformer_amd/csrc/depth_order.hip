@@ -90,22 +90,65 @@ __device__ __forceinline__ void do_key_range(int npre, const uint32_t *__restric
     kmin = mn; kmax = mx;
 }
 
+// total of the per-workgroup entry counts preprocess left (one workgroup)
+__global__ __launch_bounds__(1024) void do_entry_total_kernel(int npre, const uint32_t *__restrict__ blkent, uint32_t *__restrict__ hdr) {
+    __shared__ uint32_t s_sum[16];
+    uint32_t e = 0;
+    for (int j = threadIdx.x; j < npre; j += 1024) e += blkent[j];
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) e += (uint32_t)__shfl_xor((int)e, m);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int k = 0; k < 16; k++) t += s_sum[k];
+        hdr[DO_ETOT] = t;
+    }
+}
+// rocPRIM depth order (all P Gaussians listed): rectangles in list order, empty for the ones that emit nothing
+__global__ __launch_bounds__(256) void do_gather_rect_kernel(int P, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ tiles,
+                                                             const uint2 *__restrict__ rect, uint2 *__restrict__ orect) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= P) return;
+    const uint32_t id = perm[r];
+    orect[r] = tiles[id] > 0u ? rect[id] : make_uint2(0u, 0u);
+}
+hipError_t launch_entry_total(const GeomView &g, int P, hipStream_t s) {
+    const DepthOrderPlan pl = depth_order_plan(P);
+    hipLaunchKernelGGL(do_entry_total_kernel, dim3(1), dim3(1024), 0, s, pl.npre, g.dord.blkent, g.dord.hdr);
+    hipLaunchKernelGGL(do_gather_rect_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.perm, g.tiles, g.rect, g.orect);
+    return hipGetLastError();
+}
+
 // Level-1 histogram (count, pair-count sum per bucket): LDS per workgroup, then one global atomic per touched
 // bucket.  (A "last workgroup scans the totals" tail needs an agent-scope fence in every workgroup -- an L2
 // write-back per workgroup on this multi-XCD part, 55 us measured -- so the scan is its own one-workgroup launch.)
 __global__ __launch_bounds__(DO_CNT_THREADS) void do_hist_kernel(int P, int chunk, int nb, int npre, const uint32_t *__restrict__ depth,
                                                                  const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ blkmin,
-                                                                 const uint32_t *__restrict__ blkmax, uint32_t *__restrict__ hdr,
-                                                                 uint32_t *__restrict__ gcnt, uint32_t *__restrict__ gts) {
+                                                                 const uint32_t *__restrict__ blkmax, const uint32_t *__restrict__ blkent,
+                                                                 uint32_t *__restrict__ hdr, uint32_t *__restrict__ gcnt,
+                                                                 uint32_t *__restrict__ gts) {
     extern __shared__ uint32_t sm[];
     __shared__ uint32_t s_red[32];
+    __shared__ uint32_t s_ent[16];
+    if (blockIdx.x == 0) {                                             // workgroup 0 also totals the super-tile entries
+        uint32_t e = 0;
+        for (int j = threadIdx.x; j < npre; j += DO_CNT_THREADS) e += blkent[j];
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) e += (uint32_t)__shfl_xor((int)e, m);
+        if ((threadIdx.x & 63) == 0) s_ent[threadIdx.x >> 6] = e;
+    }
     uint32_t *h = sm, *ts = sm + nb;
     for (int b = threadIdx.x; b < 2 * nb; b += DO_CNT_THREADS) sm[b] = 0u;
     uint32_t kmin, kmax;
     do_key_range(npre, blkmin, blkmax, s_red, kmin, kmax);          // contains a barrier: sm is zeroed for everyone after it
     const uint32_t nfine = (uint32_t)nb * GSR_DO_NSUB;
     const float dmin = __uint_as_float(kmin), scale = do_scale(kmin, kmax, nfine);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[DO_KMIN] = kmin; hdr[DO_KMAX] = kmax; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                         // s_ent is complete: do_key_range has a barrier
+        uint32_t e = 0;
+        for (int k = 0; k < DO_CNT_THREADS / 64; k++) e += s_ent[k];
+        hdr[DO_KMIN] = kmin; hdr[DO_KMAX] = kmax; hdr[DO_ETOT] = e;
+    }
     const int i0 = blockIdx.x * chunk, i1 = min(P, i0 + chunk);
     for (int i = i0 + 4 * (int)threadIdx.x; i < i1; i += 4 * DO_CNT_THREADS) {
         const uint4 t4 = *reinterpret_cast<const uint4 *>(tiles + i);   // padded allocations: the tail read stays inside
@@ -158,9 +201,9 @@ __global__ __launch_bounds__(DO_CNT_THREADS) void do_bucket_scan_kernel(int nb, 
         bstart[nb] = pv; tbase[nb] = ntot;
         hdr[DO_PV] = pv; hdr[DO_NTOT] = ntot; hdr[DO_OVERFLOW] = over;
         if (host_out) {
-            host_out[0] = over; host_out[1] = pv; host_out[2] = ntot;
+            host_out[0] = over; host_out[1] = pv; host_out[2] = ntot; host_out[3] = hdr[DO_ETOT];
             __threadfence_system();
-            __hip_atomic_store(&host_out[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_out[4], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -219,7 +262,8 @@ __global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, 
                                                                         const uint32_t *__restrict__ tbase,
                                                                         const uint64_t *__restrict__ comp,
                                                                         const uint32_t *__restrict__ tiles,
-                                                                        uint32_t *__restrict__ perm, uint32_t *__restrict__ offsets) {
+                                                                        const uint2 *__restrict__ rect, uint32_t *__restrict__ perm,
+                                                                        uint32_t *__restrict__ offsets, uint2 *__restrict__ orect) {
     extern __shared__ uint64_t buf[];                              // [GSR_DO_CAP]
     __shared__ uint32_t start[GSR_DO_NSUB + 1];
     __shared__ uint32_t wsum[DO_SORT_THREADS / 64];
@@ -352,6 +396,7 @@ __global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, 
             run += tt[q];
             perm[s0 + j] = ids[q];
             offsets[s0 + j] = run;
+            orect[s0 + j] = rect[ids[q]];                           // depth-ordered copy for tile_lists.hip
         }
     }
 }
@@ -360,7 +405,7 @@ hipError_t launch_depth_order_count(const GeomView &g, int P, uint32_t *host_out
     const DepthOrderPlan pl = depth_order_plan(P);
     const DepthOrderView &d = g.dord;
     hipLaunchKernelGGL(do_hist_kernel, dim3(pl.nblk), dim3(DO_CNT_THREADS), 2 * pl.nb * sizeof(uint32_t), s, P, pl.chunk, pl.nb, pl.npre,
-                       reinterpret_cast<const uint32_t *>(g.depth), g.tiles, d.blkmin, d.blkmax, d.hdr, d.gcnt, d.gts);
+                       reinterpret_cast<const uint32_t *>(g.depth), g.tiles, d.blkmin, d.blkmax, d.blkent, d.hdr, d.gcnt, d.gts);
     hipLaunchKernelGGL(do_bucket_scan_kernel, dim3(1), dim3(DO_CNT_THREADS), 0, s, pl.nb, d.gcnt, d.gts, d.bstart, d.tbase, d.hdr, host_out, seq);
     return hipGetLastError();
 }
@@ -378,7 +423,7 @@ hipError_t launch_depth_order_place(const GeomView &g, int P, hipStream_t s) {
     hipLaunchKernelGGL(do_scatter_kernel, dim3(pl.nblk), dim3(DO_CNT_THREADS), pl.nb * sizeof(uint32_t), s, P, pl.chunk, pl.nb,
                        reinterpret_cast<const uint32_t *>(g.depth), g.tiles, d.hdr, d.bstart, d.gcur, d.comp);
     hipLaunchKernelGGL(do_local_sort_kernel, dim3(pl.nb), dim3(DO_SORT_THREADS), GSR_DO_CAP * sizeof(uint64_t), s, pl.nb, d.hdr, d.bstart,
-                       d.tbase, d.comp, g.tiles, g.perm, g.offsets);
+                       d.tbase, d.comp, g.tiles, g.rect, g.perm, g.offsets, g.orect);
     return hipGetLastError();
 }
 

@@ -24,6 +24,7 @@ static std::atomic<int> g_bwd_npx{2};
 static std::atomic<int> g_fwd_npx{2};
 static std::atomic<int> g_wpb{1};           // waves per workgroup of the compositing kernels (waves are independent)
 static std::atomic<int> g_two_level_sort{1};   // 1: rocPRIM by tile + per-tile LDS depth sort; 0: one global 64-bit-key sort      // same for the forward compositing kernel      // 8x8 pixel blocks per wave in the reverse compositing kernel (1, 2 or 4)   // output-invariant exact splat-vs-tile culling (gsr_set_option)
+static std::atomic<int> g_tile_lists{1};       // 1: tile_lists.hip (super-tile entries); 0: key emission + rocPRIM sort + range detection
 static std::atomic<int> g_depth_buckets{1};    // 0: rocPRIM radix sort + scan; 1: depth_order.hip when P is large enough; 2: always (tests)
 #define GSR_DEPTH_BUCKETS_MIN_P 32768          // below this rocPRIM's single-workgroup sort is as fast
 static float g_stage_ms[GSR_NUM_STAGES] = {0};
@@ -58,6 +59,8 @@ GeomView carve_geom(void *base, int P, size_t scan_tb, size_t dsort_tb) {
     g.clamped = (uint8_t *)take(n);
     g.perm = (uint32_t *)take(n * sizeof(uint32_t));
     g.depth_sorted = (uint32_t *)take(n * sizeof(uint32_t));
+    g.orect = (uint2 *)take(n * sizeof(uint2));
+    g.spans8 = (uint64_t *)take(n * sizeof(uint64_t));
     g.scan_temp = take(scan_tb);
     g.scan_temp_bytes = scan_tb;
     g.dsort_temp = take(dsort_tb);
@@ -69,6 +72,7 @@ GeomView carve_geom(void *base, int P, size_t scan_tb, size_t dsort_tb) {
     g.dord.tbase = (uint32_t *)take((pl.nb + 1) * sizeof(uint32_t));
     g.dord.blkmin = (uint32_t *)take(pl.npre * sizeof(uint32_t));
     g.dord.blkmax = (uint32_t *)take(pl.npre * sizeof(uint32_t));
+    g.dord.blkent = (uint32_t *)take(pl.npre * sizeof(uint32_t));
     g.dord.comp = (uint64_t *)take(n * sizeof(uint64_t));
     g.total_bytes = off;
     return g;
@@ -106,6 +110,25 @@ BinningView carve_binning(void *base, int64_t N, size_t sort_tb) {
     return b;
 }
 
+TileListView carve_tile_lists(void *base, const TileListPlan &pl, int64_t E) {
+    TileListView v;
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += align_up(bytes); return r; };
+    const size_t S = (size_t)pl.S, e = (size_t)(E > 0 ? E : 1), nseg = (size_t)(pl.nseg_max > 0 ? pl.nseg_max : 1);
+    v.mat1 = (uint32_t *)take(S * pl.nblk1 * sizeof(uint32_t));
+    v.bin_total = (uint32_t *)take(S * sizeof(uint32_t));
+    v.binstart = (uint32_t *)take((S + 1) * sizeof(uint32_t));
+    v.segbase = (uint32_t *)take((S + 1) * sizeof(uint32_t));
+    v.entries = (uint4 *)take(e * sizeof(uint4));
+    v.segcnt = (uint32_t *)take(nseg * 64 * sizeof(uint32_t));
+    v.tile_off = (uint32_t *)take(S * 64 * sizeof(uint32_t));
+    v.tile_tot = (uint32_t *)take(S * 64 * sizeof(uint32_t));
+    v.st_pairs = (uint32_t *)take(S * sizeof(uint32_t));
+    v.total_bytes = off;
+    return v;
+}
+
 static inline int grid_dim(int px) { return (px + GSR_TILE_HOST - 1) / GSR_TILE_HOST; }
 static inline int tile_bits(int W, int H) { return ceil_log2_u32((uint32_t)(grid_dim(W) * grid_dim(H))); }
 static inline int key_bits(int W, int H) { return 32 + tile_bits(W, H); }
@@ -124,7 +147,7 @@ static hipError_t any_sort_temp_bytes(int64_t N, int W, int H, size_t *bytes) {
 // produce the totals and the kernels queued behind them while the host catches up.
 struct ReadbackSlot {
     std::atomic<int> busy{0};
-    uint32_t *host = nullptr;     // 4 pinned, device-visible words
+    uint32_t *host = nullptr;     // 8 pinned, device-visible words: overflow, Pv, N, E, seq
     int device = -1;
 };
 static ReadbackSlot g_slots[8];
@@ -137,7 +160,7 @@ static ReadbackSlot *acquire_slot() {
         if (!sl.busy.compare_exchange_strong(expect, 1)) continue;
         if (sl.host && sl.device != dev) { sl.busy.store(0); continue; }
         if (!sl.host) {
-            if (hipHostMalloc((void **)&sl.host, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { sl.host = nullptr; sl.busy.store(0); return nullptr; }
+            if (hipHostMalloc((void **)&sl.host, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { sl.host = nullptr; sl.busy.store(0); return nullptr; }
             sl.device = dev;
         }
         return &sl;
@@ -151,7 +174,7 @@ static bool wait_seq(const ReadbackSlot *sl, uint32_t seq) {
     timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (uint32_t spin = 1;; spin++) {
-        if (__atomic_load_n(&sl->host[3], __ATOMIC_ACQUIRE) == seq) return true;
+        if (__atomic_load_n(&sl->host[4], __ATOMIC_ACQUIRE) == seq) return true;
         if ((spin & 0xfffffu) == 0) {
             clock_gettime(CLOCK_MONOTONIC, &t1);
             if (t1.tv_sec - t0.tv_sec > 2) return false;
@@ -201,6 +224,7 @@ const char *gsr_last_error(void) { return g_err; }
 int32_t gsr_set_option(const char *name, int32_t value) {
     if (name && !strcmp(name, "exact_tile_cull")) { g_exact_cull.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "two_level_sort")) { g_two_level_sort.store(value ? 1 : 0); return GSR_OK; }
+    if (name && !strcmp(name, "tile_lists")) { g_tile_lists.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "depth_buckets")) {
         if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARGUMENT, "depth_buckets must be 0, 1 or 2");
         g_depth_buckets.store(value); return GSR_OK;
@@ -224,6 +248,7 @@ int32_t gsr_get_option(const char *name, int32_t *value) {
     if (name && value && !strcmp(name, "bwd_blocks_per_wave")) { *value = g_bwd_npx.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "fwd_blocks_per_wave")) { *value = g_fwd_npx.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "two_level_sort")) { *value = g_two_level_sort.load(); return GSR_OK; }
+    if (name && value && !strcmp(name, "tile_lists")) { *value = g_tile_lists.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "depth_buckets")) { *value = g_depth_buckets.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "composite_waves_per_block")) { *value = g_wpb.load(); return GSR_OK; }
     return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_get_option: unknown option '%s'", name ? name : "(null)");
@@ -310,36 +335,39 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     HIP_TRY(launch_preprocess_fwd(pa, s), "preprocess launch");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "preprocess");
     tm.mark(1);
-    uint32_t n32 = 0;
+    uint32_t n32 = 0, e32 = 0;
     int P_list = P;                                   // entries of the depth-ordered list (perm / offsets)
     const int dbopt = g_depth_buckets.load();
     bool bucketed = dbopt == 2 || (dbopt == 1 && P >= GSR_DEPTH_BUCKETS_MIN_P);
     if (bucketed) {
-        uint32_t h[3] = {1u, 0u, 0u};
+        uint32_t h[4] = {1u, 0u, 0u, 0u};
         ReadbackSlot *sl = debug ? nullptr : acquire_slot();
         const uint32_t seq = sl ? (g_seq.fetch_add(1) | 0x80000000u) : 0u;
-        if (sl) sl->host[3] = 0u;
+        if (sl) sl->host[4] = 0u;
         hipError_t e = launch_depth_order_count(g, P, sl ? sl->host : nullptr, seq, s);
         if (e == hipSuccess) e = launch_depth_order_place(g, P, s);        // runs while the host waits for the totals
         if (e != hipSuccess) { release_slot(sl); return fail(GSR_ERR_HIP, "depth order: %s (%d)", hipGetErrorString(e), (int)e); }
         if (debug) HIP_TRY(hipStreamSynchronize(s), "depth order");
         tm.mark(2);
         if (sl && wait_seq(sl, seq)) {
-            h[0] = sl->host[0]; h[1] = sl->host[1]; h[2] = sl->host[2];
+            h[0] = sl->host[0]; h[1] = sl->host[1]; h[2] = sl->host[2]; h[3] = sl->host[3];
             release_slot(sl);
         } else {                                      // no slot, debug mode, or the poll timed out (slot stays retired)
-            HIP_TRY(hipMemcpyAsync(h, g.dord.hdr + DO_OVERFLOW, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read N");
+            HIP_TRY(hipMemcpyAsync(h, g.dord.hdr + DO_OVERFLOW, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read N");
             HIP_TRY(hipStreamSynchronize(s), "read N sync");
         }
+        e32 = h[3];
         if (h[0]) bucketed = false;                   // a bucket exceeds the LDS capacity: general sort below
         else { P_list = (int)h[1]; n32 = h[2]; }
     }
     if (!bucketed) {
         HIP_TRY(launch_depth_sort(g, P, s), "depth sort");
         HIP_TRY(launch_ordered_scan(g, P, s), "ordered scan");
+        HIP_TRY(launch_entry_total(g, P, s), "entry total");
         if (debug) HIP_TRY(hipStreamSynchronize(s), "depth order + scan");
         tm.mark(2);
         HIP_TRY(hipMemcpyAsync(&n32, g.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read N");
+        HIP_TRY(hipMemcpyAsync(&e32, g.dord.hdr + DO_ETOT, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read E");
         HIP_TRY(hipStreamSynchronize(s), "read N sync");
     }
     const int64_t N = (int64_t)n32;
@@ -348,24 +376,44 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     size_t sort_tb = 0;
     const int bits = key_bits(W, H);
     const int two_level = g_two_level_sort.load();
-    HIP_TRY(any_sort_temp_bytes(N, W, H, &sort_tb), "sort temp query");
-    BinningView b = carve_binning(nullptr, N, sort_tb);
-    void *bin_ptr = binning_alloc(binning_user, b.total_bytes);
-    if (!bin_ptr) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL for %zu bytes (N=%lld)", b.total_bytes, (long long)N);
-    b = carve_binning(bin_ptr, N, sort_tb);
-    tm.mark(3);
-    if (N > 0) {
-        HIP_TRY(launch_emit_keys(g, b, P_list, W, H, pa.exact_cull, two_level, s), "emit keys launch");
-        if (debug) HIP_TRY(hipStreamSynchronize(s), "emit keys");
+    const int64_t E = (int64_t)e32;
+    const TileListPlan tlp = tile_list_plan(P_list, E, W, H);
+    const bool tile_lists = g_tile_lists.load() != 0 && two_level && tlp.S <= GSR_TL_MAX_S && N > 0;
+    BinningView b;
+    TileListView tv;
+    if (tile_lists) {             // point_list first (what backward and the debug reader expect), then the entry workspace
+        const size_t pl_bytes = align_up((size_t)N * sizeof(uint32_t));
+        tv = carve_tile_lists(nullptr, tlp, E);
+        const size_t total = pl_bytes + tv.total_bytes;
+        char *bin_ptr = (char *)binning_alloc(binning_user, total);
+        if (!bin_ptr) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL for %zu bytes (N=%lld)", total, (long long)N);
+        b = carve_binning(bin_ptr, N, 0);
+        tv = carve_tile_lists(bin_ptr + pl_bytes, tlp, E);
+        if (tm.on) { g_stage_ms[3] = 0.f; g_stage_ms[5] = 0.f; }      // no key emission / range detection on this path
         tm.mark(4);
-        if (two_level) HIP_TRY(launch_sort2_by_tile(b, N, tile_bits(W, H) > 0 ? tile_bits(W, H) : 1, s), "radix sort by tile");
-        else HIP_TRY(launch_sort(b, N, bits, s), "radix sort");
-        if (debug) HIP_TRY(hipStreamSynchronize(s), "radix sort");
+        HIP_TRY(launch_tile_lists(g, tv, im, b.point_list, P_list, E, W, H, pa.exact_cull, s), "tile lists");
+        if (debug) HIP_TRY(hipStreamSynchronize(s), "tile lists");
+        tm.mark(7);
+    } else {
+        HIP_TRY(any_sort_temp_bytes(N, W, H, &sort_tb), "sort temp query");
+        b = carve_binning(nullptr, N, sort_tb);
+        void *bin_ptr = binning_alloc(binning_user, b.total_bytes);
+        if (!bin_ptr) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL for %zu bytes (N=%lld)", b.total_bytes, (long long)N);
+        b = carve_binning(bin_ptr, N, sort_tb);
+        tm.mark(3);
+        if (N > 0) {
+            HIP_TRY(launch_emit_keys(g, b, P_list, W, H, pa.exact_cull, two_level, s), "emit keys launch");
+            if (debug) HIP_TRY(hipStreamSynchronize(s), "emit keys");
+            tm.mark(4);
+            if (two_level) HIP_TRY(launch_sort2_by_tile(b, N, tile_bits(W, H) > 0 ? tile_bits(W, H) : 1, s), "radix sort by tile");
+            else HIP_TRY(launch_sort(b, N, bits, s), "radix sort");
+            if (debug) HIP_TRY(hipStreamSynchronize(s), "radix sort");
+        }
+        tm.mark(5);
+        HIP_TRY(launch_ranges(b, im, N, T, two_level, s), "tile ranges");
+        if (debug) HIP_TRY(hipStreamSynchronize(s), "tile ranges");
+        tm.mark(7);
     }
-    tm.mark(5);
-    HIP_TRY(launch_ranges(b, im, N, T, two_level, s), "tile ranges");
-    if (debug) HIP_TRY(hipStreamSynchronize(s), "tile ranges");
-    tm.mark(7);
     CompositeArgs ca;
     ca.W = W; ca.H = H; ca.gridx = gridx; ca.gridy = gridy; ca.ranges = im.ranges; ca.point_list = b.point_list;
     ca.rec = g.rec; ca.bg = bg; ca.final_T = im.final_T; ca.n_contrib = im.n_contrib; ca.out_color = out_color;
@@ -541,6 +589,23 @@ int32_t gsr_debug_read_binning(gsr_stream_t stream, int64_t N, int32_t W, int32_
         ImageView im = carve_image(const_cast<void *>(img_ws), W, H);
         const size_t T = (size_t)grid_dim(W) * grid_dim(H);
         HIP_TRY(hipMemcpy(ranges, im.ranges, T * sizeof(uint2), hipMemcpyDeviceToHost), "copy ranges");
+        if (point_list && N > 0) {
+            // canonical (tile-major) order: tile_lists.hip lays the per-tile slices out super-tile-major; the
+            // slices themselves are what the parity tests compare.  Empty tiles read (0, 0) as upstream's do.
+            uint32_t *tmp = (uint32_t *)malloc((size_t)N * sizeof(uint32_t));
+            if (!tmp) return fail(GSR_ERR_ALLOC, "host malloc");
+            size_t pos = 0;
+            for (size_t t = 0; t < T; t++) {
+                const uint32_t a = ranges[2 * t], e = ranges[2 * t + 1];
+                if (e <= a || (size_t)e > (size_t)N || pos + (e - a) > (size_t)N) { ranges[2 * t] = 0; ranges[2 * t + 1] = 0; if (e > a) { free(tmp); return fail(GSR_ERR_INVALID_ARGUMENT, "tile %zu: bad range [%u, %u)", t, a, e); } continue; }
+                memcpy(tmp + pos, point_list + a, (size_t)(e - a) * sizeof(uint32_t));
+                ranges[2 * t] = (uint32_t)pos; ranges[2 * t + 1] = (uint32_t)(pos + (e - a));
+                pos += e - a;
+            }
+            if (pos != (size_t)N) { free(tmp); return fail(GSR_ERR_INVALID_ARGUMENT, "tile ranges cover %zu of %lld pairs", pos, (long long)N); }
+            memcpy(point_list, tmp, (size_t)N * sizeof(uint32_t));
+            free(tmp);
+        }
     }
     return GSR_OK;
 }

@@ -25,7 +25,7 @@ static inline int ceil_log2_u32(uint32_t x) { int b = 0; while ((1u << b) < x &&
 #define GSR_DO_NSUB 512      // level-2 sub-buckets per bucket
 #define GSR_DO_MAXB 2048     // level-1 buckets, at most
 #define GSR_DO_MAXBLK 512    // counting / scatter workgroups, at most
-enum { DO_KMIN = 0, DO_KMAX = 1, DO_DONE = 2, DO_OVERFLOW = 3, DO_PV = 4, DO_NTOT = 5, DO_HDR_WORDS = 16 };
+enum { DO_KMIN = 0, DO_KMAX = 1, DO_DONE = 2, DO_OVERFLOW = 3, DO_PV = 4, DO_NTOT = 5, DO_ETOT = 6, DO_HDR_WORDS = 16 };
 #define GSR_DO_ZERO_WORDS (DO_HDR_WORDS + 3 * GSR_DO_MAXB)   // hdr | gcnt | gts | gcur, contiguous, zeroed by preprocess
 struct DepthOrderPlan { int nb, nblk, chunk, npre; };
 DepthOrderPlan depth_order_plan(int P);
@@ -34,6 +34,7 @@ struct DepthOrderView {
     uint32_t *gcnt, *gts, *gcur; // [GSR_DO_MAXB] bucket sizes, pair-count sums, scatter cursors
     uint32_t *bstart, *tbase;    // [nb + 1] first position / pair-count base of every bucket
     uint32_t *blkmin, *blkmax;   // [npre] depth-bit extrema of the emitting Gaussians of every preprocess workgroup
+    uint32_t *blkent;            // [npre] super-tile entries (tile_lists.hip) of every preprocess workgroup
     uint64_t *comp;              // [P] (depth bits << 32 | id), grouped by bucket
 };
 
@@ -46,6 +47,9 @@ struct GeomView {          // per-Gaussian state, P entries each
     uint8_t *clamped;      // [P] bit ch set iff SH colour channel ch was clamped at 0
     uint32_t *perm;        // [P] Gaussian ids in (depth, id) order
     uint32_t *depth_sorted;  // [P] sorted depth bits (by-product of the depth sort)
+    uint2 *orect;          // [P] tile rectangles in depth order (rect[perm[.]]; empty for a Gaussian that emits nothing)
+    uint64_t *spans8;      // [P] tile-row spans of a small rectangle (<= 8 rows, <= 15 columns, <= 2 super-tile columns):
+                           //     byte k = (c0 - x0) | (c1 - x0) << 4 of row y0 + k; ~0 = not representable, recompute
     void *scan_temp;
     size_t scan_temp_bytes;
     void *dsort_temp;
@@ -100,7 +104,7 @@ hipError_t launch_scan(const GeomView &g, int P, hipStream_t s);
 
 hipError_t sort_temp_bytes(int64_t N, int bits, size_t *bytes);
 hipError_t launch_emit_keys(const GeomView &g, const BinningView &b, int P, int W, int H, int exact_cull, int two_level, hipStream_t s);
-// histogram + bucket scan -> hdr totals; host_out (pinned, may be NULL) receives {overflow, Pv, N, seq}
+// histogram + bucket scan -> hdr totals; host_out (pinned, may be NULL) receives {overflow, Pv, N, E, seq}
 hipError_t launch_depth_order_count(const GeomView &g, int P, uint32_t *host_out, uint32_t seq, hipStream_t s);
 hipError_t launch_depth_order_place(const GeomView &g, int P, hipStream_t s);   // scatter, per-bucket order + scan -> perm, offsets
 hipError_t sort2_temp_bytes(int64_t N, int tile_bits, size_t *bytes);
@@ -109,6 +113,26 @@ hipError_t depth_sort_temp_bytes(int P, size_t *bytes);
 hipError_t launch_depth_sort(const GeomView &g, int P, hipStream_t s);
 hipError_t launch_ordered_scan(const GeomView &g, int P, hipStream_t s);
 hipError_t launch_sort(const BinningView &b, int64_t N, int bits, hipStream_t s);
+hipError_t launch_entry_total(const GeomView &g, int P, hipStream_t s);          // hdr[DO_ETOT] and orect when depth_order.hip did not run
+
+// ---- tile_lists.hip: per-tile depth-ordered lists through (Gaussian, super-tile) entries ----
+#define GSR_TL_SEG 256       // entries per level-2 segment
+#define GSR_TL_MAX_S 512     // super-tiles (8 x 8 tiles) the LDS lane masks of level 1 cover: 4096 x 2176 pixels
+struct TileListPlan { int SX, SY, S, nblk1; int64_t nseg_max; };
+TileListPlan tile_list_plan(int P_list, int64_t E, int W, int H);
+struct TileListView {
+    uint32_t *mat1;              // [S][nblk1] entries per (super-tile, level-1 workgroup), scanned in place
+    uint32_t *bin_total;         // [S]
+    uint32_t *binstart, *segbase;    // [S + 1] first entry / first segment of every super-tile
+    uint4 *entries;              // [E] (Gaussian id, -, tile mask lo, hi), grouped by super-tile, depth order inside
+    uint32_t *segcnt;            // [nseg_max][64] entries of the segment that reach the tile, scanned in place
+    uint32_t *tile_off, *tile_tot;   // [S][64]
+    uint32_t *st_pairs;          // [S]
+    size_t total_bytes;
+};
+TileListView carve_tile_lists(void *base, const TileListPlan &pl, int64_t E);
+hipError_t launch_tile_lists(const GeomView &g, const TileListView &v, const ImageView &im, uint32_t *point_list, int P_list, int64_t E,
+                             int W, int H, int exact_cull, hipStream_t s);
 hipError_t launch_ranges(const BinningView &b, const ImageView &im, int64_t N, int T, int two_level, hipStream_t s);
 
 struct CompositeArgs {

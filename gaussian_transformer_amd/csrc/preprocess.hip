@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
     uint2 rect_out = make_uint2(0u, 0u);
     uint8_t clamp_out = 0;
     float depth_out = 0.f;
+    uint64_t spans_out = ~0ull;
 
     const float p[3] = {a.means3D[3 * si], a.means3D[3 * si + 1], a.means3D[3 * si + 2]};
     float pv[3];
@@ -71,6 +72,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
                 const float opacity = (RAW) ? act_sigmoid(a.opacities[si]) : a.opacities[si];
                 float tau = 0.f;
                 int pairs = area;
+                // the row spans go to tile_lists.hip in one word when the rectangle is small enough
+                const bool small = (y1 - y0) <= 8 && (x1 - x0) <= 15 && (((x1 - 1) >> 3) - (x0 >> 3)) <= 1;
+                uint64_t sp = 0ull;
                 if (a.exact_cull) {                      // count only the tiles the ellipse can reach
                     tau = cull_tau(opacity);
                     const CullParams cp = make_cull(conA, conB, conC, tau);
@@ -79,8 +83,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
                         int c0, c1;
                         tile_row_span(cp, px, py, conA, conB, ty, a.W, a.H, x0, x1, c0, c1);
                         pairs += c1 - c0;
+                        sp |= (uint64_t)(uint32_t)((c0 - x0) | ((c1 - x0) << 4)) << (8 * ((ty - y0) & 7));
                     }
+                } else {
+                    for (int k = 0; k < y1 - y0 && k < 8; k++) sp |= (uint64_t)(uint32_t)((x1 - x0) << 4) << (8 * k);
                 }
+                spans_out = small ? sp : ~0ull;
                 float rgb[3];
                 if (a.colors_precomp) {
                     rgb[0] = a.colors_precomp[3 * si]; rgb[1] = a.colors_precomp[3 * si + 1]; rgb[2] = a.colors_precomp[3 * si + 2];
@@ -120,18 +128,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
         a.g.depth[si] = depth_out;
         a.g.rect[si] = rect_out;
         a.g.tiles[si] = tiles_out;
+        a.g.spans8[si] = spans_out;
         a.g.clamped[si] = clamp_out;
         a.radii[si] = radius_out;
     }
     // depth-bit extrema of this workgroup's emitting Gaussians (depth_order.hip derives its bucket map from them)
-    __shared__ uint32_t s_mn[4], s_mx[4];
+    __shared__ uint32_t s_mn[4], s_mx[4], s_en[4];
     const bool emits = live && tiles_out > 0u;
+    // (Gaussian, super-tile) entries of tile_lists.hip: super-tiles of 8 x 8 tiles under the tile rectangle
+    uint32_t ent = 0u;
+    if (emits) {
+        const uint32_t x0 = rect_out.x & 0xffffu, x1 = rect_out.x >> 16, y0 = rect_out.y & 0xffffu, y1 = rect_out.y >> 16;
+        ent = (((x1 + 7u) >> 3) - (x0 >> 3)) * (((y1 + 7u) >> 3) - (y0 >> 3));
+    }
     uint32_t mn = emits ? __float_as_uint(depth_out) : 0xffffffffu, mx = emits ? __float_as_uint(depth_out) : 0u;
 #pragma unroll
-    for (int m = 32; m > 0; m >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, m)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, m)); }
-    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+    for (int m = 32; m > 0; m >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, m)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, m));
+        ent += (uint32_t)__shfl_xor((int)ent, m);
+    }
+    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; s_en[threadIdx.x >> 6] = ent; }
     __syncthreads();
     if (threadIdx.x == 0) {
+        a.g.dord.blkent[blockIdx.x] = s_en[0] + s_en[1] + s_en[2] + s_en[3];
         a.g.dord.blkmin[blockIdx.x] = min(min(s_mn[0], s_mn[1]), min(s_mn[2], s_mn[3]));
         a.g.dord.blkmax[blockIdx.x] = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
     }

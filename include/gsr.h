@@ -133,6 +133,10 @@ int32_t gsr_debug_read_image_state(gsr_stream_t stream, int32_t W, int32_t H, co
  *   "two_level_sort" (default 1): put the Gaussians in (depth bits, id) order first, emit the pairs in that
  *        order and finish with a STABLE radix sort on the tile id only; identical resulting order to
  *        0 = one global radix sort on tile<<32|depth.  Speed only.
+ *   "tile_lists" (default 1): build the per-tile lists from (Gaussian, super-tile) entries (csrc/tile_lists.hip)
+ *        instead of emitting and radix-sorting (tile, Gaussian) pairs; needs two_level_sort = 1 and an image of at
+ *        most 512 super-tiles of 128 x 128 pixels, otherwise the sort path runs.  Same per-tile lists; point_list
+ *        is then laid out super-tile-major (ranges[] say where each tile's slice is).  Speed only.
  *   "depth_buckets" (0, 1 or 2; default 1): how the Gaussians are put in depth order.  0 = rocPRIM radix sort
  *        + scan; 1 = the bucketed depth order of csrc/depth_order.hip when P >= 32768 (falls back to 0 by itself
  *        when a depth bucket does not fit in LDS); 2 = bucketed for every P (tests).  Same order.  Speed only.

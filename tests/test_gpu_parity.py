@@ -53,7 +53,7 @@ def upstream_tile_rule():
     _lib.set_option("exact_tile_cull", 1)
 
 
-@pytest.mark.parametrize("two_level", [0, 1])
+@pytest.mark.parametrize("two_level", [0, 1, 2])     # 0: one global sort, 1: depth order + rocPRIM by-tile sort, 2: depth order + tile_lists.hip
 @pytest.mark.parametrize("kw", [
     dict(P=3000, width=160, height=112, sh_degree=3, s0=0.03, seed=0),
     dict(P=1500, width=100, height=57, sh_degree=1, s0=0.06, seed=1, zmin=0.05, zmax=5.0),   # culled splats, ragged tiles
@@ -63,11 +63,27 @@ def upstream_tile_rule():
 ])
 def test_stages_bit_exact_against_oracle(kw, two_level, upstream_tile_rule):
     from gaussian_transformer_amd import _lib
-    _lib.set_option("two_level_sort", two_level)
+    _lib.set_option("two_level_sort", 1 if two_level else 0)
+    _lib.set_option("tile_lists", 1 if two_level == 2 else 0)
     try:
         _check_stages_bit_exact(kw, two_level)
     finally:
         _lib.set_option("two_level_sort", 1)
+        _lib.set_option("tile_lists", 1)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(P=20000, width=3840, height=40, sh_degree=0, s0=0.02, seed=11),         # 30 x 1 super-tiles, ragged right edge
+    dict(P=4000, width=200, height=1100, sh_degree=0, s0=0.05, seed=12),         # 2 x 9 super-tiles, tall splats
+    dict(P=300, width=700, height=500, sh_degree=0, s0=1.5, seed=13),            # splats over dozens of super-tiles
+    dict(P=70000, width=640, height=360, sh_degree=0, s0=0.01, seed=14),         # 137 level-1 workgroups, many segments
+    dict(P=3000, width=8300, height=130, sh_degree=0, s0=0.02, seed=15),         # 65 x 2 super-tiles... still <= 512
+    dict(P=3000, width=8300, height=1100, sh_degree=0, s0=0.02, seed=16),        # 585 super-tiles > 512: rocPRIM path
+])
+def test_tile_lists_bit_exact(kw, upstream_tile_rule):
+    """tile_lists.hip (default path) against the oracle's sorted pair list, per tile, on grids that stress the
+    super-tile geometry; the last case exceeds the LDS lane-mask capacity and must take the sort path by itself."""
+    _check_stages_bit_exact(dict(kw), 2)
 
 
 @pytest.mark.parametrize("kw", [
