@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void emit_keys_kernel(int P, int W, int H, int
                                                         const uint32_t *__restrict__ perm,
                                                         const uint32_t *__restrict__ tiles,
                                                         const uint32_t *__restrict__ offsets,
-                                                        const uint2 *__restrict__ rect, const float *__restrict__ rec,
+                                                        const uint4 *__restrict__ rect, const float *__restrict__ rec,
                                                         uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                         uint32_t *__restrict__ tkeys, uint32_t *__restrict__ ids) {
     const int lane = threadIdx.x & 63;
@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void emit_keys_kernel(int P, int W, int H, int
     const uint32_t out_total = offsets[min(g0 + 63, P - 1)] - out_start;
     if (out_total == 0) return;                           // wave-uniform
     const int gc = (int)perm[g < P ? g : P - 1];          // Gaussian id of this lane
-    const uint2 rc = rect[gc];
+    const uint4 rc4 = rect[gc];
+    const uint2 rc = make_uint2(rc4.x, rc4.y);
     const uint32_t rh = (rc.y >> 16) - (rc.y & 0xffffu);
     // level-1 items = tile rows of the 3-sigma rectangle; splats that emit nothing are not walked at all
     const uint32_t nrows = (g < P && tiles[gc] > 0u) ? rh : 0u;

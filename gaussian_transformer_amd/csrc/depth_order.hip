@@ -107,11 +107,11 @@ __global__ __launch_bounds__(1024) void do_entry_total_kernel(int npre, const ui
 }
 // rocPRIM depth order (all P Gaussians listed): rectangles in list order, empty for the ones that emit nothing
 __global__ __launch_bounds__(256) void do_gather_rect_kernel(int P, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ tiles,
-                                                             const uint2 *__restrict__ rect, uint2 *__restrict__ orect) {
+                                                             const uint4 *__restrict__ rect, uint4 *__restrict__ orect) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= P) return;
     const uint32_t id = perm[r];
-    orect[r] = tiles[id] > 0u ? rect[id] : make_uint2(0u, 0u);
+    orect[r] = tiles[id] > 0u ? rect[id] : make_uint4(0u, 0u, 0u, 0u);
 }
 hipError_t launch_entry_total(const GeomView &g, int P, hipStream_t s) {
     const DepthOrderPlan pl = depth_order_plan(P);
@@ -257,13 +257,13 @@ __global__ __launch_bounds__(DO_CNT_THREADS) void do_scatter_kernel(int P, int c
 }
 
 // one workgroup per level-1 bucket: order its keys in LDS, then scan the pair counts of the ordered slice
-__global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, const uint32_t *__restrict__ hdr,
+__global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, int need_offsets, const uint32_t *__restrict__ hdr,
                                                                         const uint32_t *__restrict__ bstart,
                                                                         const uint32_t *__restrict__ tbase,
                                                                         const uint64_t *__restrict__ comp,
                                                                         const uint32_t *__restrict__ tiles,
-                                                                        const uint2 *__restrict__ rect, uint32_t *__restrict__ perm,
-                                                                        uint32_t *__restrict__ offsets, uint2 *__restrict__ orect) {
+                                                                        const uint4 *__restrict__ rect, uint32_t *__restrict__ perm,
+                                                                        uint32_t *__restrict__ offsets, uint4 *__restrict__ orect) {
     extern __shared__ uint64_t buf[];                              // [GSR_DO_CAP]
     __shared__ uint32_t start[GSR_DO_NSUB + 1];
     __shared__ uint32_t wsum[DO_SORT_THREADS / 64];
@@ -371,6 +371,14 @@ __global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, 
         }
     }
     __syncthreads();
+    if (!need_offsets) {                                           // grid-uniform: tile_lists.hip only wants the ordered records
+        for (int j = tid; j < n; j += DO_SORT_THREADS) {
+            const uint32_t id = sid[j];
+            perm[s0 + j] = id;
+            orect[s0 + j] = rect[id];
+        }
+        return;
+    }
     // ---- scan of the pair counts in sorted order: thread tid owns positions [tid*k, tid*k + k) ----
     const int k = (n + DO_SORT_THREADS - 1) / DO_SORT_THREADS;     // <= DO_ITEMS
     uint32_t ids[DO_ITEMS], tt[DO_ITEMS];
@@ -396,7 +404,6 @@ __global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, 
             run += tt[q];
             perm[s0 + j] = ids[q];
             offsets[s0 + j] = run;
-            orect[s0 + j] = rect[ids[q]];                           // depth-ordered copy for tile_lists.hip
         }
     }
 }
@@ -410,7 +417,7 @@ hipError_t launch_depth_order_count(const GeomView &g, int P, uint32_t *host_out
     return hipGetLastError();
 }
 
-hipError_t launch_depth_order_place(const GeomView &g, int P, hipStream_t s) {
+hipError_t launch_depth_order_place(const GeomView &g, int P, int need_offsets, hipStream_t s) {
     const DepthOrderPlan pl = depth_order_plan(P);
     const DepthOrderView &d = g.dord;
     static bool attr_set = false;   // benign race: the attribute is idempotent
@@ -422,7 +429,7 @@ hipError_t launch_depth_order_place(const GeomView &g, int P, hipStream_t s) {
     }
     hipLaunchKernelGGL(do_scatter_kernel, dim3(pl.nblk), dim3(DO_CNT_THREADS), pl.nb * sizeof(uint32_t), s, P, pl.chunk, pl.nb,
                        reinterpret_cast<const uint32_t *>(g.depth), g.tiles, d.hdr, d.bstart, d.gcur, d.comp);
-    hipLaunchKernelGGL(do_local_sort_kernel, dim3(pl.nb), dim3(DO_SORT_THREADS), GSR_DO_CAP * sizeof(uint64_t), s, pl.nb, d.hdr, d.bstart,
+    hipLaunchKernelGGL(do_local_sort_kernel, dim3(pl.nb), dim3(DO_SORT_THREADS), GSR_DO_CAP * sizeof(uint64_t), s, pl.nb, need_offsets, d.hdr, d.bstart,
                        d.tbase, d.comp, g.tiles, g.rect, g.perm, g.offsets, g.orect);
     return hipGetLastError();
 }

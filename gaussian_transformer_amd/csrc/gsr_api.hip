@@ -53,14 +53,15 @@ GeomView carve_geom(void *base, int P, size_t scan_tb, size_t dsort_tb) {
     auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += align_up(bytes); return r; };
     g.rec = (float *)take(n * GSR_REC_FLOATS * sizeof(float));
     g.depth = (float *)take(n * sizeof(float));
-    g.rect = (uint2 *)take(n * sizeof(uint2));
+    g.rect = (uint4 *)take(n * sizeof(uint4));
     g.tiles = (uint32_t *)take(n * sizeof(uint32_t));
     g.offsets = (uint32_t *)take(n * sizeof(uint32_t));
     g.clamped = (uint8_t *)take(n);
     g.perm = (uint32_t *)take(n * sizeof(uint32_t));
     g.depth_sorted = (uint32_t *)take(n * sizeof(uint32_t));
-    g.orect = (uint2 *)take(n * sizeof(uint2));
-    g.spans8 = (uint64_t *)take(n * sizeof(uint64_t));
+    g.orect = (uint4 *)take(n * sizeof(uint4));
+    g.tl_mat1 = (uint32_t *)take((size_t)GSR_TL_MAX_S * ((n + GSR_TL_L1 - 1) / GSR_TL_L1) * sizeof(uint32_t));
+    g.tl_bin_total = (uint32_t *)take(GSR_TL_MAX_S * sizeof(uint32_t));
     g.scan_temp = take(scan_tb);
     g.scan_temp_bytes = scan_tb;
     g.dsort_temp = take(dsort_tb);
@@ -116,10 +117,9 @@ TileListView carve_tile_lists(void *base, const TileListPlan &pl, int64_t E) {
     size_t off = 0;
     auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += align_up(bytes); return r; };
     const size_t S = (size_t)pl.S, e = (size_t)(E > 0 ? E : 1), nseg = (size_t)(pl.nseg_max > 0 ? pl.nseg_max : 1);
-    v.mat1 = (uint32_t *)take(S * pl.nblk1 * sizeof(uint32_t));
-    v.bin_total = (uint32_t *)take(S * sizeof(uint32_t));
     v.binstart = (uint32_t *)take((S + 1) * sizeof(uint32_t));
     v.segbase = (uint32_t *)take((S + 1) * sizeof(uint32_t));
+    v.seg_super = (uint32_t *)take(nseg * sizeof(uint32_t));
     v.entries = (uint4 *)take(e * sizeof(uint4));
     v.segcnt = (uint32_t *)take(nseg * 64 * sizeof(uint32_t));
     v.tile_off = (uint32_t *)take(S * 64 * sizeof(uint32_t));
@@ -336,6 +336,10 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     if (debug) HIP_TRY(hipStreamSynchronize(s), "preprocess");
     tm.mark(1);
     uint32_t n32 = 0, e32 = 0;
+    const int two_level = g_two_level_sort.load();
+    // whether tile_lists.hip builds the per-tile lists is known up front (image size, options): its level-1 counting
+    // is queued before the host waits for N, and the depth order then skips the scan only key emission needs
+    const bool want_tile_lists = g_tile_lists.load() != 0 && two_level && tile_list_plan(P, 0, W, H).S <= GSR_TL_MAX_S;
     int P_list = P;                                   // entries of the depth-ordered list (perm / offsets)
     const int dbopt = g_depth_buckets.load();
     bool bucketed = dbopt == 2 || (dbopt == 1 && P >= GSR_DEPTH_BUCKETS_MIN_P);
@@ -345,7 +349,8 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
         const uint32_t seq = sl ? (g_seq.fetch_add(1) | 0x80000000u) : 0u;
         if (sl) sl->host[4] = 0u;
         hipError_t e = launch_depth_order_count(g, P, sl ? sl->host : nullptr, seq, s);
-        if (e == hipSuccess) e = launch_depth_order_place(g, P, s);        // runs while the host waits for the totals
+        if (e == hipSuccess) e = launch_depth_order_place(g, P, want_tile_lists ? 0 : 1, s);   // runs while the host waits for the totals
+        if (e == hipSuccess && want_tile_lists) e = launch_tile_lists_count(g, P, g.dord.hdr, W, H, s);
         if (e != hipSuccess) { release_slot(sl); return fail(GSR_ERR_HIP, "depth order: %s (%d)", hipGetErrorString(e), (int)e); }
         if (debug) HIP_TRY(hipStreamSynchronize(s), "depth order");
         tm.mark(2);
@@ -364,6 +369,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
         HIP_TRY(launch_depth_sort(g, P, s), "depth sort");
         HIP_TRY(launch_ordered_scan(g, P, s), "ordered scan");
         HIP_TRY(launch_entry_total(g, P, s), "entry total");
+        if (want_tile_lists) HIP_TRY(launch_tile_lists_count(g, P, nullptr, W, H, s), "tile lists: count");
         if (debug) HIP_TRY(hipStreamSynchronize(s), "depth order + scan");
         tm.mark(2);
         HIP_TRY(hipMemcpyAsync(&n32, g.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read N");
@@ -375,10 +381,9 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
 
     size_t sort_tb = 0;
     const int bits = key_bits(W, H);
-    const int two_level = g_two_level_sort.load();
     const int64_t E = (int64_t)e32;
-    const TileListPlan tlp = tile_list_plan(P_list, E, W, H);
-    const bool tile_lists = g_tile_lists.load() != 0 && two_level && tlp.S <= GSR_TL_MAX_S && N > 0;
+    const TileListPlan tlp = tile_list_plan(P, E, W, H);
+    const bool tile_lists = want_tile_lists && N > 0;
     BinningView b;
     TileListView tv;
     if (tile_lists) {             // point_list first (what backward and the debug reader expect), then the entry workspace
@@ -391,7 +396,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
         tv = carve_tile_lists(bin_ptr + pl_bytes, tlp, E);
         if (tm.on) { g_stage_ms[3] = 0.f; g_stage_ms[5] = 0.f; }      // no key emission / range detection on this path
         tm.mark(4);
-        HIP_TRY(launch_tile_lists(g, tv, im, b.point_list, P_list, E, W, H, pa.exact_cull, s), "tile lists");
+        HIP_TRY(launch_tile_lists(g, tv, im, b.point_list, P, P_list, E, W, H, pa.exact_cull, s), "tile lists");
         if (debug) HIP_TRY(hipStreamSynchronize(s), "tile lists");
         tm.mark(7);
     } else {
@@ -581,8 +586,11 @@ int32_t gsr_debug_read_binning(gsr_stream_t stream, int64_t N, int32_t W, int32_
     HIP_TRY(hipStreamSynchronize(s), "sync");
     if (N > 0 && binning_ws) {
         BinningView b = carve_binning(const_cast<void *>(binning_ws), N, 0);
-        // global-sort mode: tile<<32|depth ; meaningless in two-level mode
-        if (keys_sorted) HIP_TRY(hipMemcpy(keys_sorted, b.keys_sorted, (size_t)N * 8, hipMemcpyDeviceToHost), "copy keys");
+        // the 64-bit tile<<32|depth keys only exist in global-sort mode (the other layouts may not even span that region)
+        if (keys_sorted) {
+            if (g_two_level_sort.load() == 0) HIP_TRY(hipMemcpy(keys_sorted, b.keys_sorted, (size_t)N * 8, hipMemcpyDeviceToHost), "copy keys");
+            else memset(keys_sorted, 0, (size_t)N * 8);
+        }
         if (point_list) HIP_TRY(hipMemcpy(point_list, b.point_list, (size_t)N * 4, hipMemcpyDeviceToHost), "copy point list");
     }
     if (ranges && img_ws) {

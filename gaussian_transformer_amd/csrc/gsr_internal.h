@@ -41,15 +41,17 @@ struct DepthOrderView {
 struct GeomView {          // per-Gaussian state, P entries each
     float *rec;            // [P][12]
     float *depth;          // [P]
-    uint2 *rect;           // [P] (x0 | x1<<16, y0 | y1<<16)
+    uint4 *rect;           // [P] (x0 | x1<<16, y0 | y1<<16, row spans lo, hi): tile rectangle + the tile-row spans of a
+                           //     small rectangle (<= 8 rows, <= 15 columns, <= 2 super-tile columns) in one word:
+                           //     byte k = (c0 - x0) | (c1 - x0) << 4 of row y0 + k; all ones = not representable
     uint32_t *tiles;       // [P] (Gaussian,tile) pairs emitted (== rect area when exact culling is off)
     uint32_t *offsets;     // [P] inclusive scan of tiles[perm[.]] (depth order)
     uint8_t *clamped;      // [P] bit ch set iff SH colour channel ch was clamped at 0
     uint32_t *perm;        // [P] Gaussian ids in (depth, id) order
     uint32_t *depth_sorted;  // [P] sorted depth bits (by-product of the depth sort)
-    uint2 *orect;          // [P] tile rectangles in depth order (rect[perm[.]]; empty for a Gaussian that emits nothing)
-    uint64_t *spans8;      // [P] tile-row spans of a small rectangle (<= 8 rows, <= 15 columns, <= 2 super-tile columns):
-                           //     byte k = (c0 - x0) | (c1 - x0) << 4 of row y0 + k; ~0 = not representable, recompute
+    uint4 *orect;          // [P] rect[perm[.]]: the same records in depth order (empty rectangle for a Gaussian that emits nothing)
+    uint32_t *tl_mat1;     // [GSR_TL_MAX_S][ceil(P / 512)] tile_lists.hip level-1 count matrix (filled before N is known)
+    uint32_t *tl_bin_total;    // [GSR_TL_MAX_S]
     void *scan_temp;
     size_t scan_temp_bytes;
     void *dsort_temp;
@@ -106,7 +108,8 @@ hipError_t sort_temp_bytes(int64_t N, int bits, size_t *bytes);
 hipError_t launch_emit_keys(const GeomView &g, const BinningView &b, int P, int W, int H, int exact_cull, int two_level, hipStream_t s);
 // histogram + bucket scan -> hdr totals; host_out (pinned, may be NULL) receives {overflow, Pv, N, E, seq}
 hipError_t launch_depth_order_count(const GeomView &g, int P, uint32_t *host_out, uint32_t seq, hipStream_t s);
-hipError_t launch_depth_order_place(const GeomView &g, int P, hipStream_t s);   // scatter, per-bucket order + scan -> perm, offsets
+// scatter, per-bucket order (+ scan of the pair counts when need_offsets) -> perm, orect, offsets
+hipError_t launch_depth_order_place(const GeomView &g, int P, int need_offsets, hipStream_t s);
 hipError_t sort2_temp_bytes(int64_t N, int tile_bits, size_t *bytes);
 hipError_t launch_sort2_by_tile(const BinningView &b, int64_t N, int tile_bits, hipStream_t s);
 hipError_t depth_sort_temp_bytes(int P, size_t *bytes);
@@ -117,13 +120,13 @@ hipError_t launch_entry_total(const GeomView &g, int P, hipStream_t s);         
 
 // ---- tile_lists.hip: per-tile depth-ordered lists through (Gaussian, super-tile) entries ----
 #define GSR_TL_SEG 256       // entries per level-2 segment
+#define GSR_TL_L1 512        // Gaussians per level-1 workgroup
 #define GSR_TL_MAX_S 512     // super-tiles (8 x 8 tiles) the LDS lane masks of level 1 cover: 4096 x 2176 pixels
 struct TileListPlan { int SX, SY, S, nblk1; int64_t nseg_max; };
 TileListPlan tile_list_plan(int P_list, int64_t E, int W, int H);
 struct TileListView {
-    uint32_t *mat1;              // [S][nblk1] entries per (super-tile, level-1 workgroup), scanned in place
-    uint32_t *bin_total;         // [S]
     uint32_t *binstart, *segbase;    // [S + 1] first entry / first segment of every super-tile
+    uint32_t *seg_super;         // [nseg_max] super-tile of every segment
     uint4 *entries;              // [E] (Gaussian id, -, tile mask lo, hi), grouped by super-tile, depth order inside
     uint32_t *segcnt;            // [nseg_max][64] entries of the segment that reach the tile, scanned in place
     uint32_t *tile_off, *tile_tot;   // [S][64]
@@ -131,8 +134,11 @@ struct TileListView {
     size_t total_bytes;
 };
 TileListView carve_tile_lists(void *base, const TileListPlan &pl, int64_t E);
-hipError_t launch_tile_lists(const GeomView &g, const TileListView &v, const ImageView &im, uint32_t *point_list, int P_list, int64_t E,
-                             int W, int H, int exact_cull, hipStream_t s);
+// level-1 counting (needs neither N nor E: queued before the host reads them back); hdr: depth_order.hip's header
+// (list length at [DO_PV], nothing to do when [DO_OVERFLOW]) or NULL (the list holds all P Gaussians)
+hipError_t launch_tile_lists_count(const GeomView &g, int P, const uint32_t *hdr, int W, int H, hipStream_t s);
+hipError_t launch_tile_lists(const GeomView &g, const TileListView &v, const ImageView &im, uint32_t *point_list, int P, int P_list,
+                             int64_t E, int W, int H, int exact_cull, hipStream_t s);
 hipError_t launch_ranges(const BinningView &b, const ImageView &im, int64_t N, int T, int two_level, hipStream_t s);
 
 struct CompositeArgs {

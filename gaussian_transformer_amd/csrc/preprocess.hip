@@ -23,10 +23,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
     int radius_out = 0;
     uint32_t tiles_out = 0;
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-    uint2 rect_out = make_uint2(0u, 0u);
+    uint4 rect_out = make_uint4(0u, 0u, ~0u, ~0u);
     uint8_t clamp_out = 0;
     float depth_out = 0.f;
-    uint64_t spans_out = ~0ull;
 
     const float p[3] = {a.means3D[3 * si], a.means3D[3 * si + 1], a.means3D[3 * si + 2]};
     float pv[3];
@@ -88,7 +87,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
                 } else {
                     for (int k = 0; k < y1 - y0 && k < 8; k++) sp |= (uint64_t)(uint32_t)((x1 - x0) << 4) << (8 * k);
                 }
-                spans_out = small ? sp : ~0ull;
+                if (!small) sp = ~0ull;
                 float rgb[3];
                 if (a.colors_precomp) {
                     rgb[0] = a.colors_precomp[3 * si]; rgb[1] = a.colors_precomp[3 * si + 1]; rgb[2] = a.colors_precomp[3 * si + 2];
@@ -115,7 +114,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
                 radius_out = radius;
                 tiles_out = (uint32_t)pairs;
                 depth_out = pv[2];
-                rect_out = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
+                rect_out = make_uint4((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16), (uint32_t)sp, (uint32_t)(sp >> 32));
                 r0 = make_float4(px, py, conA, conB);
                 r1 = make_float4(conC, opacity, rgb[0], rgb[1]);
                 r2 = make_float4(rgb[2], pv[2], tau, 0.f);
@@ -128,7 +127,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
         a.g.depth[si] = depth_out;
         a.g.rect[si] = rect_out;
         a.g.tiles[si] = tiles_out;
-        a.g.spans8[si] = spans_out;
         a.g.clamped[si] = clamp_out;
         a.radii[si] = radius_out;
     }

@@ -27,17 +27,17 @@
 
 namespace gsr {
 
-#define TL_L1_THREADS 512
+#define TL_L1_THREADS GSR_TL_L1
 #define TL_L1_WAVES (TL_L1_THREADS / 64)
 #define TL_SEG GSR_TL_SEG
 
-TileListPlan tile_list_plan(int P_list, int64_t E, int W, int H) {
+TileListPlan tile_list_plan(int P, int64_t E, int W, int H) {
     TileListPlan p;
     const int gridx = (W + GSR_TILE - 1) / GSR_TILE, gridy = (H + GSR_TILE - 1) / GSR_TILE;
     p.SX = (gridx + 7) / 8;
     p.SY = (gridy + 7) / 8;
     p.S = p.SX * p.SY;
-    p.nblk1 = (P_list > 0 ? P_list + TL_L1_THREADS - 1 : TL_L1_THREADS) / TL_L1_THREADS;
+    p.nblk1 = (P > 0 ? P + TL_L1_THREADS - 1 : TL_L1_THREADS) / TL_L1_THREADS;    // matrix row stride: all P Gaussians
     p.nseg_max = (int64_t)(E > 0 ? E : 0) / TL_SEG + p.S;
     return p;
 }
@@ -62,22 +62,26 @@ __device__ __forceinline__ uint32_t tl_wave_sum(uint32_t v) {
 }
 
 struct SuperRect { int x0, x1, y0, y1, sx0, sx1, sy0, sy1; };
-__device__ __forceinline__ SuperRect super_rect(uint2 rc) {
+__device__ __forceinline__ SuperRect super_rect(uint4 rc, int SX, int SY) {
     SuperRect r;
     r.x0 = (int)(rc.x & 0xffffu); r.x1 = (int)(rc.x >> 16); r.y0 = (int)(rc.y & 0xffffu); r.y1 = (int)(rc.y >> 16);
-    r.sx0 = r.x0 >> 3; r.sx1 = (r.x1 + 7) >> 3; r.sy0 = r.y0 >> 3; r.sy1 = (r.y1 + 7) >> 3;
+    // tile rectangles lie inside the grid; the clamp only bounds the loops should a record ever be garbage
+    r.sx0 = r.x0 >> 3; r.sx1 = min((r.x1 + 7) >> 3, SX); r.sy0 = r.y0 >> 3; r.sy1 = min((r.y1 + 7) >> 3, SY);
     return r;
 }
 
 // ---- level 1a: entries per (super-tile, workgroup) ----
-__global__ __launch_bounds__(TL_L1_THREADS) void tl_count_kernel(int Pl, int SX, int S, int nblk1, const uint2 *__restrict__ orect,
-                                                                 uint32_t *__restrict__ mat1) {
+__global__ __launch_bounds__(TL_L1_THREADS) void tl_count_kernel(int P, const uint32_t *__restrict__ hdr, int SX, int SY, int nblk1,
+                                                                 const uint4 *__restrict__ orect, uint32_t *__restrict__ mat1) {
     extern __shared__ uint32_t cnt[];
+    const int S = SX * SY;
+    if (hdr && hdr[DO_OVERFLOW]) return;                                 // grid-uniform: depth_order.hip gave up, the caller re-runs this
+    const int Pl = hdr ? min((int)hdr[DO_PV], P) : P;                    // length of the depth-ordered list
     for (int b = threadIdx.x; b < S; b += TL_L1_THREADS) cnt[b] = 0u;
     __syncthreads();
     const int r = blockIdx.x * TL_L1_THREADS + threadIdx.x;
     if (r < Pl) {
-        const SuperRect q = super_rect(orect[r]);
+        const SuperRect q = super_rect(orect[r], SX, SY);
         if (q.x1 > q.x0)
             for (int sy = q.sy0; sy < q.sy1; sy++)
                 for (int sx = q.sx0; sx < q.sx1; sx++) atomicAdd(&cnt[sy * SX + sx], 1u);
@@ -109,13 +113,13 @@ __global__ __launch_bounds__(1024) void tl_binscan_kernel(int nblk1, uint32_t *_
 
 // ---- level 1c: place the entries (stable), computing their tile masks ----
 struct TlScatterArgs {
-    int Pl, SX, S, nblk1, W, H, exact_cull;
+    int Pl, SX, SY, S, nblk1, W, H, exact_cull;
     const uint32_t *perm;
-    const uint2 *orect;
-    const uint64_t *spans8;
+    const uint4 *orect;
     const float *rec;
     const uint32_t *mat1, *bin_total;
     uint32_t *binstart, *segbase;    // [S + 1], written by workgroup 0
+    uint32_t *seg_super;             // [segments] owning super-tile, written by workgroup 0
     uint4 *entries;
 };
 __global__ __launch_bounds__(TL_L1_THREADS) void tl_scatter_kernel(TlScatterArgs a) {
@@ -126,9 +130,16 @@ __global__ __launch_bounds__(TL_L1_THREADS) void tl_scatter_kernel(TlScatterArgs
     uint32_t *bstart = woff + TL_L1_WAVES * S;                           // [S + 1]
     __shared__ uint32_t wsum[2][TL_L1_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // every global read this workgroup needs is issued up front: the kernel is a chain of round trips otherwise
+    const int r = blockIdx.x * TL_L1_THREADS + tid;
+    uint4 rc = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t id = 0u;
+    if (r < a.Pl) { rc = a.orect[r]; id = a.perm[r]; }
+    const uint32_t my_total = tid < S ? a.bin_total[tid] : 0u;
+    const uint32_t my_before = tid < S ? a.mat1[(size_t)tid * a.nblk1 + blockIdx.x] : 0u;
     for (int i = tid; i < TL_L1_WAVES * S; i += TL_L1_THREADS) masks[i] = 0ull;
     {   // list start of every super-tile and its first segment (S <= TL_L1_THREADS: one per thread)
-        const uint32_t v = tid < S ? a.bin_total[tid] : 0u;
+        const uint32_t v = my_total;
         const uint32_t sg = tid < S ? max(1u, (v + TL_SEG - 1) / TL_SEG) : 0u;
         const uint32_t iv = tl_wave_incl_scan(v, lane), is = tl_wave_incl_scan(sg, lane);
         if (lane == 63) { wsum[0][w] = iv; wsum[1][w] = is; }
@@ -140,28 +151,26 @@ __global__ __launch_bounds__(TL_L1_THREADS) void tl_scatter_kernel(TlScatterArgs
         if (blockIdx.x == 0 && tid < S) {
             a.binstart[tid] = ev; a.segbase[tid] = es;
             if (tid == S - 1) { a.binstart[S] = ev + v; a.segbase[S] = es + sg; }
+            for (uint32_t k = 0; k < sg; k++) a.seg_super[es + k] = (uint32_t)tid;
         }
     }
     __syncthreads();
-    const int r = blockIdx.x * TL_L1_THREADS + tid;
-    bool emits = false;
-    SuperRect q = {};
-    if (r < a.Pl) { q = super_rect(a.orect[r]); emits = q.x1 > q.x0; }
+    const SuperRect q = super_rect(rc, a.SX, a.SY);
+    const bool emits = q.x1 > q.x0;
     if (emits)
         for (int sy = q.sy0; sy < q.sy1; sy++)
             for (int sx = q.sx0; sx < q.sx1; sx++)
                 atomicOr(reinterpret_cast<unsigned long long *>(&masks[w * S + sy * a.SX + sx]), 1ull << lane);
     __syncthreads();
     if (tid < S) {
-        uint32_t run = bstart[tid] + a.mat1[(size_t)tid * a.nblk1 + blockIdx.x];
+        uint32_t run = bstart[tid] + my_before;
 #pragma unroll
         for (int k = 0; k < TL_L1_WAVES; k++) { woff[k * S + tid] = run; run += (uint32_t)__popcll(masks[k * S + tid]); }
     }
     __syncthreads();
     if (!emits) return;
-    const uint32_t id = a.perm[r];
     const uint64_t below = (1ull << lane) - 1ull;
-    const uint64_t sp = a.spans8[id];
+    const uint64_t sp = (uint64_t)rc.z | ((uint64_t)rc.w << 32);
     if (sp != ~0ull) {
         // small rectangle (<= 8 rows, <= 2 x 2 super-tiles): the masks come straight from preprocess's row spans
         const int xs = q.x0 & 7, ys = q.y0 & 7, rows = q.y1 - q.y0;
@@ -233,23 +242,14 @@ __device__ __forceinline__ uint64_t wave_transpose64(uint64_t x, int lane) {
     return x;
 }
 
-// which super-tile owns segment `seg` (wave-uniform): segbase[s] <= seg < segbase[s + 1]
-__device__ __forceinline__ int tl_find_super(const uint32_t *__restrict__ segbase, int S, uint32_t seg) {
-    int lo = 0, hi = S;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (segbase[mid] <= seg) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
 // ---- level 2a: one wave per segment, lane = tile: how many of the segment's entries reach the tile ----
 __global__ __launch_bounds__(256) void tl_segcount_kernel(int S, const uint32_t *__restrict__ segbase, const uint32_t *__restrict__ binstart,
-                                                          const uint4 *__restrict__ entries, uint32_t *__restrict__ segcnt) {
+                                                          const uint32_t *__restrict__ seg_super, const uint4 *__restrict__ entries,
+                                                          uint32_t *__restrict__ segcnt) {
     const int lane = threadIdx.x & 63;
     const uint32_t seg = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (seg >= segbase[S]) return;                                       // wave-uniform
-    const int s = tl_find_super(segbase, S, seg);
+    const int s = (int)seg_super[seg];
     const uint32_t e0 = binstart[s] + (seg - segbase[s]) * TL_SEG, eend = binstart[s + 1];
     const int n = eend > e0 ? (int)min((uint32_t)TL_SEG, eend - e0) : 0;
     uint32_t c = 0;
@@ -306,14 +306,15 @@ __global__ __launch_bounds__(1024) void tl_tilescan_kernel(const uint32_t *__res
 
 // ---- level 2c: one wave per segment, lane = tile: append the ids of the entries whose mask has the lane's bit ----
 __global__ __launch_bounds__(256) void tl_expand_kernel(int S, int SX, int gridx, int gridy, const uint32_t *__restrict__ segbase,
-                                                        const uint32_t *__restrict__ binstart, const uint4 *__restrict__ entries,
+                                                        const uint32_t *__restrict__ binstart, const uint32_t *__restrict__ seg_super,
+                                                        const uint4 *__restrict__ entries,
                                                         const uint32_t *__restrict__ segcnt, const uint32_t *__restrict__ tile_off,
                                                         const uint32_t *__restrict__ tile_tot, const uint32_t *__restrict__ st_pairs,
                                                         uint32_t *__restrict__ point_list, uint2 *__restrict__ ranges) {
     const int lane = threadIdx.x & 63;
     const uint32_t seg = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (seg >= segbase[S]) return;                                       // wave-uniform
-    const int s = tl_find_super(segbase, S, seg);
+    const int s = (int)seg_super[seg];
     uint32_t before = 0;                                                 // pairs of the super-tiles before this one
     for (int k = lane; k < s; k += 64) before += st_pairs[k];
     before = tl_wave_sum(before);
@@ -345,24 +346,30 @@ __global__ __launch_bounds__(256) void tl_expand_kernel(int S, int SX, int gridx
     }
 }
 
-hipError_t launch_tile_lists(const GeomView &g, const TileListView &v, const ImageView &im, uint32_t *point_list, int P_list, int64_t E,
-                             int W, int H, int exact_cull, hipStream_t s) {
-    const TileListPlan pl = tile_list_plan(P_list, E, W, H);
+hipError_t launch_tile_lists_count(const GeomView &g, int P, const uint32_t *hdr, int W, int H, hipStream_t s) {
+    const TileListPlan pl = tile_list_plan(P, 0, W, H);
+    hipLaunchKernelGGL(tl_count_kernel, dim3(pl.nblk1), dim3(TL_L1_THREADS), pl.S * sizeof(uint32_t), s, P, hdr, pl.SX, pl.SY, pl.nblk1,
+                       g.orect, g.tl_mat1);
+    hipLaunchKernelGGL(tl_binscan_kernel, dim3(pl.S), dim3(1024), 0, s, pl.nblk1, g.tl_mat1, g.tl_bin_total);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_lists(const GeomView &g, const TileListView &v, const ImageView &im, uint32_t *point_list, int P, int P_list,
+                             int64_t E, int W, int H, int exact_cull, hipStream_t s) {
+    const TileListPlan pl = tile_list_plan(P, E, W, H);
     const int gridx = (W + GSR_TILE - 1) / GSR_TILE, gridy = (H + GSR_TILE - 1) / GSR_TILE;
-    hipLaunchKernelGGL(tl_count_kernel, dim3(pl.nblk1), dim3(TL_L1_THREADS), pl.S * sizeof(uint32_t), s, P_list, pl.SX, pl.S, pl.nblk1,
-                       g.orect, v.mat1);
-    hipLaunchKernelGGL(tl_binscan_kernel, dim3(pl.S), dim3(1024), 0, s, pl.nblk1, v.mat1, v.bin_total);
     TlScatterArgs a;
-    a.Pl = P_list; a.SX = pl.SX; a.S = pl.S; a.nblk1 = pl.nblk1; a.W = W; a.H = H; a.exact_cull = exact_cull;
-    a.perm = g.perm; a.orect = g.orect; a.spans8 = g.spans8; a.rec = g.rec; a.mat1 = v.mat1; a.bin_total = v.bin_total;
-    a.binstart = v.binstart; a.segbase = v.segbase; a.entries = v.entries;
+    a.Pl = P_list; a.SX = pl.SX; a.SY = pl.SY; a.S = pl.S; a.nblk1 = pl.nblk1; a.W = W; a.H = H; a.exact_cull = exact_cull;
+    a.perm = g.perm; a.orect = g.orect; a.rec = g.rec; a.mat1 = g.tl_mat1; a.bin_total = g.tl_bin_total;
+    a.binstart = v.binstart; a.segbase = v.segbase; a.seg_super = v.seg_super; a.entries = v.entries;
     const size_t lds = (size_t)TL_L1_WAVES * pl.S * (sizeof(uint64_t) + sizeof(uint32_t)) + (pl.S + 1) * sizeof(uint32_t);
-    hipLaunchKernelGGL(tl_scatter_kernel, dim3(pl.nblk1), dim3(TL_L1_THREADS), lds, s, a);
+    const int nblk_used = (P_list > 0 ? P_list + TL_L1_THREADS - 1 : TL_L1_THREADS) / TL_L1_THREADS;   // workgroup 0 always runs
+    hipLaunchKernelGGL(tl_scatter_kernel, dim3(nblk_used), dim3(TL_L1_THREADS), lds, s, a);
     const unsigned sgrid = (unsigned)((pl.nseg_max + 3) / 4);
-    hipLaunchKernelGGL(tl_segcount_kernel, dim3(sgrid), dim3(256), 0, s, pl.S, v.segbase, v.binstart, v.entries, v.segcnt);
+    hipLaunchKernelGGL(tl_segcount_kernel, dim3(sgrid), dim3(256), 0, s, pl.S, v.segbase, v.binstart, v.seg_super, v.entries, v.segcnt);
     hipLaunchKernelGGL(tl_tilescan_kernel, dim3(pl.S), dim3(1024), 0, s, v.segbase, v.segcnt, v.tile_off, v.tile_tot, v.st_pairs);
-    hipLaunchKernelGGL(tl_expand_kernel, dim3(sgrid), dim3(256), 0, s, pl.S, pl.SX, gridx, gridy, v.segbase, v.binstart, v.entries, v.segcnt,
-                       v.tile_off, v.tile_tot, v.st_pairs, point_list, im.ranges);
+    hipLaunchKernelGGL(tl_expand_kernel, dim3(sgrid), dim3(256), 0, s, pl.S, pl.SX, gridx, gridy, v.segbase, v.binstart, v.seg_super, v.entries,
+                       v.segcnt, v.tile_off, v.tile_tot, v.st_pairs, point_list, im.ranges);
     return hipGetLastError();
 }
 

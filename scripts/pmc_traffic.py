@@ -9,6 +9,8 @@ import csv, glob, json, os, sys, collections
 d, tag, out = sys.argv[1], sys.argv[2], sys.argv[3]
 STAGES = [("composite_bwd_kernel", "bwd.composite"), ("composite_fwd_kernel", "fwd.composite"),
           ("preprocess_fwd_kernel", "fwd.preprocess"), ("pergauss_bwd_kernel", "bwd.pergauss"),
+          ("do_hist_kernel", "fwd.depth_order+scan"), ("do_bucket_scan_kernel", "fwd.depth_order+scan"), ("do_scatter_kernel", "fwd.depth_order+scan"),
+          ("do_local_sort_kernel", "fwd.depth_order+scan"), ("tl_", "fwd.sort"),
           ("emit_keys_kernel", "fwd.emit_keys"), ("tile_ranges", "fwd.ranges"), ("scan", "fwd.depth_order+scan"), ("onesweep", "fwd.sort"), ("histogram", "fwd.sort"), ("radix_sort", "fwd.sort"), ("rocprim", "fwd.sort")]
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 steps = 0
