@@ -257,7 +257,8 @@ __global__ __launch_bounds__(DO_CNT_THREADS) void do_scatter_kernel(int P, int c
 }
 
 // one workgroup per level-1 bucket: order its keys in LDS, then scan the pair counts of the ordered slice
-__global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, int need_offsets, const uint32_t *__restrict__ hdr,
+template <bool NEED_OFFSETS>
+__global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, const uint32_t *__restrict__ hdr,
                                                                         const uint32_t *__restrict__ bstart,
                                                                         const uint32_t *__restrict__ tbase,
                                                                         const uint64_t *__restrict__ comp,
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, 
                                                                         const uint4 *__restrict__ rect, uint32_t *__restrict__ perm,
                                                                         uint32_t *__restrict__ offsets, uint4 *__restrict__ orect) {
     extern __shared__ uint64_t buf[];                              // [GSR_DO_CAP]
-    __shared__ uint32_t start[GSR_DO_NSUB + 1];
+    __shared__ uint32_t start[GSR_DO_NSUB + 1], cur[GSR_DO_NSUB];
     __shared__ uint32_t wsum[DO_SORT_THREADS / 64];
     __shared__ uint32_t s_max;
     if (hdr[DO_OVERFLOW]) return;                                  // grid-uniform
@@ -278,41 +279,36 @@ __global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, 
     if (tid <= GSR_DO_NSUB) start[tid] = 0u;
     if (tid == 0) s_max = 0u;
     __syncthreads();
-    // ---- sub-bucket histogram; the items stay in registers until they are placed ----
-    {
-        uint64_t c[DO_ITEMS];
-        uint32_t sr[DO_ITEMS];                                     // sub-bucket | arrival rank << 16
+    // ---- sub-bucket histogram, then placement with a second pass over the keys (L2-resident): nothing is held in
+    //      registers across the barriers, which keeps two workgroups per CU resident ----
 #pragma unroll
-        for (int q = 0; q < DO_ITEMS; q++) {
-            const int j = tid + q * DO_SORT_THREADS;
-            c[q] = 0ull; sr[q] = 0u;
-            if (j < n) c[q] = comp[s0 + j];
+    for (int q = 0; q < DO_ITEMS; q++) {
+        const int j = tid + q * DO_SORT_THREADS;
+        if (j < n) {
+            const uint32_t key = (uint32_t)(comp[s0 + j] >> 32);
+            atomicAdd(&start[do_fine(key, dmin, scale, nfine) & (GSR_DO_NSUB - 1)], 1u);
         }
-#pragma unroll
-        for (int q = 0; q < DO_ITEMS; q++) {
-            const int j = tid + q * DO_SORT_THREADS;
-            if (j < n) {
-                const uint32_t sub = do_fine((uint32_t)(c[q] >> 32), dmin, scale, nfine) & (GSR_DO_NSUB - 1);
-                sr[q] = sub | (atomicAdd(&start[sub], 1u) << 16);
-            }
-        }
+    }
+    __syncthreads();
+    {   // exclusive scan of the sub-bucket counts (thread t < 512 owns sub-bucket t) + their maximum
+        const uint32_t v = tid < GSR_DO_NSUB ? start[tid] : 0u;
+        const uint32_t mx = wave_max_u32(v);
+        const uint32_t incl = wave_incl_scan_u32(v, lane);
+        if (lane == 63) { wsum[w] = incl; atomicMax(&s_max, mx); }
         __syncthreads();
-        {   // exclusive scan of the sub-bucket counts (thread t < 512 owns sub-bucket t) + their maximum
-            const uint32_t v = tid < GSR_DO_NSUB ? start[tid] : 0u;
-            const uint32_t mx = wave_max_u32(v);
-            const uint32_t incl = wave_incl_scan_u32(v, lane);
-            if (lane == 63) { wsum[w] = incl; atomicMax(&s_max, mx); }
-            __syncthreads();
-            uint32_t ex = incl - v;
-            for (int k = 0; k < w; k++) ex += wsum[k];
-            if (tid < GSR_DO_NSUB) start[tid] = ex;
-            if (tid == GSR_DO_NSUB) start[GSR_DO_NSUB] = (uint32_t)n;
-        }
-        __syncthreads();
+        uint32_t ex = incl - v;
+        for (int k = 0; k < w; k++) ex += wsum[k];
+        if (tid < GSR_DO_NSUB) { start[tid] = ex; cur[tid] = ex; }
+        if (tid == GSR_DO_NSUB) start[GSR_DO_NSUB] = (uint32_t)n;
+    }
+    __syncthreads();
 #pragma unroll
-        for (int q = 0; q < DO_ITEMS; q++) {
-            const int j = tid + q * DO_SORT_THREADS;
-            if (j < n) buf[start[sr[q] & 0xffffu] + (sr[q] >> 16)] = c[q];
+    for (int q = 0; q < DO_ITEMS; q++) {
+        const int j = tid + q * DO_SORT_THREADS;
+        if (j < n) {
+            const uint64_t c = comp[s0 + j];
+            const uint32_t sub = do_fine((uint32_t)(c >> 32), dmin, scale, nfine) & (GSR_DO_NSUB - 1);
+            buf[atomicAdd(&cur[sub], 1u)] = c;                     // arrival order inside the sub-bucket is irrelevant
         }
     }
     __syncthreads();
@@ -371,7 +367,7 @@ __global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, 
         }
     }
     __syncthreads();
-    if (!need_offsets) {                                           // grid-uniform: tile_lists.hip only wants the ordered records
+    if (!NEED_OFFSETS) {                                           // tile_lists.hip only wants the ordered records
         for (int j = tid; j < n; j += DO_SORT_THREADS) {
             const uint32_t id = sid[j];
             perm[s0 + j] = id;
@@ -422,15 +418,22 @@ hipError_t launch_depth_order_place(const GeomView &g, int P, int need_offsets, 
     const DepthOrderView &d = g.dord;
     static bool attr_set = false;   // benign race: the attribute is idempotent
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(do_local_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(do_local_sort_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            GSR_DO_CAP * (int)sizeof(uint64_t));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(do_local_sort_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    GSR_DO_CAP * (int)sizeof(uint64_t));
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     hipLaunchKernelGGL(do_scatter_kernel, dim3(pl.nblk), dim3(DO_CNT_THREADS), pl.nb * sizeof(uint32_t), s, P, pl.chunk, pl.nb,
                        reinterpret_cast<const uint32_t *>(g.depth), g.tiles, d.hdr, d.bstart, d.gcur, d.comp);
-    hipLaunchKernelGGL(do_local_sort_kernel, dim3(pl.nb), dim3(DO_SORT_THREADS), GSR_DO_CAP * sizeof(uint64_t), s, pl.nb, need_offsets, d.hdr, d.bstart,
-                       d.tbase, d.comp, g.tiles, g.rect, g.perm, g.offsets, g.orect);
+    if (need_offsets)
+        hipLaunchKernelGGL(do_local_sort_kernel<true>, dim3(pl.nb), dim3(DO_SORT_THREADS), GSR_DO_CAP * sizeof(uint64_t), s, pl.nb, d.hdr, d.bstart,
+                           d.tbase, d.comp, g.tiles, g.rect, g.perm, g.offsets, g.orect);
+    else
+        hipLaunchKernelGGL(do_local_sort_kernel<false>, dim3(pl.nb), dim3(DO_SORT_THREADS), GSR_DO_CAP * sizeof(uint64_t), s, pl.nb, d.hdr, d.bstart,
+                           d.tbase, d.comp, g.tiles, g.rect, g.perm, g.offsets, g.orect);
     return hipGetLastError();
 }
 

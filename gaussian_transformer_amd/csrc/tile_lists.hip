@@ -30,6 +30,7 @@ namespace gsr {
 #define TL_L1_THREADS GSR_TL_L1
 #define TL_L1_WAVES (TL_L1_THREADS / 64)
 #define TL_SEG GSR_TL_SEG
+#define TL_STAGE 2048             // ids one wave stages in LDS before writing them out (a 256-entry segment yields ~1300)
 
 TileListPlan tile_list_plan(int P, int64_t E, int W, int H) {
     TileListPlan p;
@@ -172,29 +173,37 @@ __global__ __launch_bounds__(TL_L1_THREADS) void tl_scatter_kernel(TlScatterArgs
     const uint64_t below = (1ull << lane) - 1ull;
     const uint64_t sp = (uint64_t)rc.z | ((uint64_t)rc.w << 32);
     if (sp != ~0ull) {
-        // small rectangle (<= 8 rows, <= 2 x 2 super-tiles): the masks come straight from preprocess's row spans
-        const int xs = q.x0 & 7, ys = q.y0 & 7, rows = q.y1 - q.y0;
-        uint64_t m[2][2] = {{0ull, 0ull}, {0ull, 0ull}};
+        // small rectangle (<= 8 rows, <= 2 x 2 super-tiles): the masks come straight from preprocess's row spans.
+        // Rows 0..7 of the rectangle are first packed one byte each (constant shifts: k is unrolled) per super-tile
+        // column, then the 8-byte strips move down by y0 & 7 rows into the upper / lower super-tile.
+        const int xs = q.x0 & 7, ys = q.y0 & 7;
+        uint32_t c0lo = 0u, c0hi = 0u, c1lo = 0u, c1hi = 0u;                // strip of column j: rows 0-3 | rows 4-7
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            if (k < rows) {
-                const uint32_t bb = (uint32_t)(sp >> (8 * k)) & 0xffu;
-                const uint32_t c0 = bb & 15u, c1 = bb >> 4;
-                const uint32_t w24 = (((1u << c1) - 1u) & ~((1u << c0) - 1u)) << xs;
-                const int rs = ys + k, sh = (rs & 7) * 8;
-                const uint64_t lo = (uint64_t)(w24 & 0xffu) << sh, hi = (uint64_t)((w24 >> 8) & 0xffu) << sh;
-                if (rs < 8) { m[0][0] |= lo; m[0][1] |= hi; } else { m[1][0] |= lo; m[1][1] |= hi; }
+            const uint32_t bb = k < 4 ? (rc.z >> (8 * k)) & 0xffu : (rc.w >> (8 * (k - 4))) & 0xffu;   // 0 beyond the last row
+            const uint32_t lo4 = bb & 15u, hi4 = bb >> 4;
+            const uint32_t w24 = (((1u << hi4) - 1u) & ~((1u << lo4) - 1u)) << xs;
+            const uint32_t b0 = w24 & 0xffu, b1 = (w24 >> 8) & 0xffu;
+            if (k < 4) { c0lo |= b0 << (8 * k); c1lo |= b1 << (8 * k); } else { c0hi |= b0 << (8 * (k - 4)); c1hi |= b1 << (8 * (k - 4)); }
+        }
+        const uint64_t strip[2] = {(uint64_t)c0lo | ((uint64_t)c0hi << 32), (uint64_t)c1lo | ((uint64_t)c1hi << 32)};
+        const int sh = 8 * ys;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            if (q.sx0 + j < q.sx1) {
+                const uint64_t up = strip[j] << sh;                          // rows that stay in super row sy0
+                const uint64_t dn = sh ? strip[j] >> (64 - sh) : 0ull;       // rows that spill into sy0 + 1
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    if (q.sy0 + i < q.sy1) {
+                        const uint64_t mm = i ? dn : up;
+                        const int bin = (q.sy0 + i) * a.SX + q.sx0 + j;
+                        const uint32_t slot = woff[w * S + bin] + (uint32_t)__popcll(masks[w * S + bin] & below);
+                        a.entries[slot] = make_uint4(id, 0u, (uint32_t)mm, (uint32_t)(mm >> 32));
+                    }
+                }
             }
         }
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-                if (q.sy0 + i < q.sy1 && q.sx0 + j < q.sx1) {
-                    const int bin = (q.sy0 + i) * a.SX + q.sx0 + j;
-                    const uint32_t slot = woff[w * S + bin] + (uint32_t)__popcll(masks[w * S + bin] & below);
-                    a.entries[slot] = make_uint4(id, 0u, (uint32_t)m[i][j], (uint32_t)(m[i][j] >> 32));
-                }
         return;
     }
     // large rectangle: evaluate the ellipse-vs-tile-row spans here, 8 tile rows (one super row) at a time
@@ -242,6 +251,20 @@ __device__ __forceinline__ uint64_t wave_transpose64(uint64_t x, int lane) {
     return x;
 }
 
+// the same for the TL_SEG / 64 groups of a segment at once: independent exchange chains hide each other's latency
+__device__ __forceinline__ void wave_transpose64x4(uint64_t x[TL_SEG / 64], int lane) {
+#pragma unroll
+    for (int j = 32; j >= 1; j >>= 1) {
+        const uint64_t M = j == 32 ? 0x00000000ffffffffull : j == 16 ? 0x0000ffff0000ffffull : j == 8 ? 0x00ff00ff00ff00ffull
+                         : j == 4 ? 0x0f0f0f0f0f0f0f0full : j == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
+        uint64_t o[TL_SEG / 64];
+#pragma unroll
+        for (int q = 0; q < TL_SEG / 64; q++) o[q] = (uint64_t)__shfl_xor((unsigned long long)x[q], j);
+#pragma unroll
+        for (int q = 0; q < TL_SEG / 64; q++) x[q] = (lane & j) ? ((x[q] & ~M) | ((o[q] & ~M) >> j)) : ((x[q] & M) | ((o[q] & M) << j));
+    }
+}
+
 // ---- level 2a: one wave per segment, lane = tile: how many of the segment's entries reach the tile ----
 __global__ __launch_bounds__(256) void tl_segcount_kernel(int S, const uint32_t *__restrict__ segbase, const uint32_t *__restrict__ binstart,
                                                           const uint32_t *__restrict__ seg_super, const uint4 *__restrict__ entries,
@@ -252,16 +275,17 @@ __global__ __launch_bounds__(256) void tl_segcount_kernel(int S, const uint32_t 
     const int s = (int)seg_super[seg];
     const uint32_t e0 = binstart[s] + (seg - segbase[s]) * TL_SEG, eend = binstart[s + 1];
     const int n = eend > e0 ? (int)min((uint32_t)TL_SEG, eend - e0) : 0;
-    uint32_t c = 0;
+    uint64_t m[TL_SEG / 64];
 #pragma unroll
     for (int qq = 0; qq < TL_SEG / 64; qq++) {
-        if (qq * 64 < n) {                                               // wave-uniform
-            const int j = qq * 64 + lane;
-            uint64_t m = 0ull;
-            if (j < n) { const uint4 e = entries[e0 + j]; m = (uint64_t)e.z | ((uint64_t)e.w << 32); }
-            c += (uint32_t)__popcll(wave_transpose64(m, lane));          // lane = tile: entries of this group that reach it
-        }
+        const int j = qq * 64 + lane;
+        m[qq] = 0ull;
+        if (j < n) { const uint4 e = entries[e0 + j]; m[qq] = (uint64_t)e.z | ((uint64_t)e.w << 32); }
     }
+    wave_transpose64x4(m, lane);                                         // lane = tile: bit l of m[qq] = entry qq*64+l reaches it
+    uint32_t c = 0;
+#pragma unroll
+    for (int qq = 0; qq < TL_SEG / 64; qq++) c += (uint32_t)__popcll(m[qq]);
     segcnt[(size_t)seg * 64 + lane] = c;
 }
 
@@ -326,23 +350,60 @@ __global__ __launch_bounds__(256) void tl_expand_kernel(int S, int SX, int gridx
     const uint32_t e0 = binstart[s] + (seg - segbase[s]) * TL_SEG, eend = binstart[s + 1];
     const int n = eend > e0 ? (int)min((uint32_t)TL_SEG, eend - e0) : 0;
     uint32_t cursor = off + segcnt[(size_t)seg * 64 + lane];
+    uint64_t col[TL_SEG / 64];
+    uint32_t eid[TL_SEG / 64];
 #pragma unroll
     for (int qq = 0; qq < TL_SEG / 64; qq++) {
-        if (qq * 64 < n) {                                               // wave-uniform
-            const int j = qq * 64 + lane;
-            uint64_t m = 0ull;
-            uint32_t eid = 0u;
-            if (j < n) { const uint4 e = entries[e0 + j]; eid = e.x; m = (uint64_t)e.z | ((uint64_t)e.w << 32); }
-            uint64_t col = wave_transpose64(m, lane);                    // bit l: entry l of this group reaches tile `lane`
-            const int iters = (int)tl_wave_max((uint32_t)__popcll(col));
-            for (int it = 0; it < iters; it++) {                         // wave-uniform trip count: every lane feeds the shuffle
-                const bool has = col != 0ull;
-                const int l = has ? __ffsll((unsigned long long)col) - 1 : 0;
-                const uint32_t gid = (uint32_t)__shfl((int)eid, l);
-                if (has) point_list[cursor++] = gid;
-                col &= col - 1ull;
+        const int j = qq * 64 + lane;
+        col[qq] = 0ull; eid[qq] = 0u;
+        if (j < n) { const uint4 e = entries[e0 + j]; eid[qq] = e.x; col[qq] = (uint64_t)e.z | ((uint64_t)e.w << 32); }
+    }
+    wave_transpose64x4(col, lane);                                       // bit l of col[qq]: entry qq*64+l reaches tile `lane`
+    // The ids first go to a wave-private LDS slice, grouped by tile, and leave as one contiguous run per tile:
+    // appended straight to global memory they are 4-byte stores into ~250 open cache lines per wave, which L2
+    // evicts half empty (3.4 x write amplification measured).
+    __shared__ uint32_t stage[4][TL_STAGE];
+    __shared__ uint8_t stage_tile[4][TL_STAGE];                          // owning tile (= lane) of every staged id
+    uint32_t *my = stage[threadIdx.x >> 6];
+    uint8_t *my_tile = stage_tile[threadIdx.x >> 6];
+    uint32_t pc[TL_SEG / 64], cnt = 0, most = 0;
+#pragma unroll
+    for (int qq = 0; qq < TL_SEG / 64; qq++) { pc[qq] = (uint32_t)__popcll(col[qq]); cnt += pc[qq]; most = max(most, pc[qq]); }
+    const uint32_t lincl = tl_wave_incl_scan(cnt, lane);
+    const uint32_t lstart = lincl - cnt;                                 // this tile's run inside the slice
+    const uint32_t total = (uint32_t)__shfl((int)lincl, 63);
+    const bool staged = total <= TL_STAGE;                               // wave-uniform
+    // the groups append in order, so each has its own cursor and the four streams advance together
+    uint32_t cur[TL_SEG / 64];
+    {
+        uint32_t run = staged ? lstart : cursor;
+#pragma unroll
+        for (int qq = 0; qq < TL_SEG / 64; qq++) { cur[qq] = run; run += pc[qq]; }
+    }
+    const int iters = (int)tl_wave_max(most);
+    for (int it = 0; it < iters; it++) {                                 // wave-uniform trip count: every lane feeds the shuffles
+#pragma unroll
+        for (int qq = 0; qq < TL_SEG / 64; qq++) {
+            const bool has = col[qq] != 0ull;
+            const int l = has ? __ffsll((unsigned long long)col[qq]) - 1 : 0;
+            const uint32_t gid = (uint32_t)__shfl((int)eid[qq], l);
+            if (has) {
+                if (staged) { my[cur[qq]] = gid; my_tile[cur[qq]] = (uint8_t)lane; } else point_list[cur[qq]] = gid;
+                cur[qq]++;
             }
+            col[qq] &= col[qq] - 1ull;
         }
+    }
+    if (!staged) return;
+    __builtin_amdgcn_wave_barrier();
+    // flattened copy-out: element i of the slice belongs to tile my_tile[i] and goes to i + (cursor - lstart) of that tile,
+    // so consecutive lanes write consecutive words of a tile's run
+    const uint32_t delta = cursor - lstart;
+    for (uint32_t i = lane; i < ((total + 63u) & ~63u); i += 64) {       // wave-uniform trip count: every lane feeds the shuffle
+        const bool in = i < total;
+        const int t = in ? (int)my_tile[i] : 0;
+        const uint32_t d = (uint32_t)__shfl((int)delta, t);
+        if (in) point_list[i + d] = my[i];
     }
 }
 
