@@ -26,7 +26,7 @@ static std::atomic<int> g_wpb{1};           // waves per workgroup of the compos
 static std::atomic<int> g_two_level_sort{1};   // 1: rocPRIM by tile + per-tile LDS depth sort; 0: one global 64-bit-key sort      // same for the forward compositing kernel      // 8x8 pixel blocks per wave in the reverse compositing kernel (1, 2 or 4)   // output-invariant exact splat-vs-tile culling (gsr_set_option)
 static std::atomic<int> g_tile_lists{1};       // 1: tile_lists.hip (super-tile entries); 0: key emission + rocPRIM sort + range detection
 static std::atomic<int> g_depth_buckets{1};    // 0: rocPRIM radix sort + scan; 1: depth_order.hip when P is large enough; 2: always (tests)
-#define GSR_DEPTH_BUCKETS_MIN_P 32768          // below this rocPRIM's single-workgroup sort is as fast
+#define GSR_DEPTH_BUCKETS_MIN_P 1024           // measured at P = 10 k: 25 us against 48 us for rocPRIM sort + scan + copy-back
 static float g_stage_ms[GSR_NUM_STAGES] = {0};
 static const char *const k_stage_names[GSR_NUM_STAGES] = {
     "fwd.preprocess", "fwd.depth_order+scan", "fwd.readback_N", "fwd.emit_keys", "fwd.sort", "fwd.ranges", "(unused)",

@@ -138,7 +138,7 @@ int32_t gsr_debug_read_image_state(gsr_stream_t stream, int32_t W, int32_t H, co
  *        most 512 super-tiles of 128 x 128 pixels, otherwise the sort path runs.  Same per-tile lists; point_list
  *        is then laid out super-tile-major (ranges[] say where each tile's slice is).  Speed only.
  *   "depth_buckets" (0, 1 or 2; default 1): how the Gaussians are put in depth order.  0 = rocPRIM radix sort
- *        + scan; 1 = the bucketed depth order of csrc/depth_order.hip when P >= 32768 (falls back to 0 by itself
+ *        + scan; 1 = the bucketed depth order of csrc/depth_order.hip when P >= 1024 (falls back to 0 by itself
  *        when a depth bucket does not fit in LDS); 2 = bucketed for every P (tests).  Same order.  Speed only.
  *   "composite_waves_per_block" (1, 2 or 4; default 1): wave64s per workgroup of the compositing
  *        kernels.  The waves never synchronise, so 1 lets every wave retire (and be replaced) alone.

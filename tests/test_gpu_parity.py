@@ -53,7 +53,7 @@ def upstream_tile_rule():
     _lib.set_option("exact_tile_cull", 1)
 
 
-@pytest.mark.parametrize("two_level", [0, 1, 2])     # 0: one global sort, 1: depth order + rocPRIM by-tile sort, 2: depth order + tile_lists.hip
+@pytest.mark.parametrize("two_level", [0, 1, 2])     # 0: one global sort, 1: rocPRIM depth sort + rocPRIM by-tile sort, 2: depth_order.hip + tile_lists.hip
 @pytest.mark.parametrize("kw", [
     dict(P=3000, width=160, height=112, sh_degree=3, s0=0.03, seed=0),
     dict(P=1500, width=100, height=57, sh_degree=1, s0=0.06, seed=1, zmin=0.05, zmax=5.0),   # culled splats, ragged tiles
@@ -65,11 +65,13 @@ def test_stages_bit_exact_against_oracle(kw, two_level, upstream_tile_rule):
     from gaussian_transformer_amd import _lib
     _lib.set_option("two_level_sort", 1 if two_level else 0)
     _lib.set_option("tile_lists", 1 if two_level == 2 else 0)
+    _lib.set_option("depth_buckets", 1 if two_level == 2 else 0)
     try:
         _check_stages_bit_exact(kw, two_level)
     finally:
         _lib.set_option("two_level_sort", 1)
         _lib.set_option("tile_lists", 1)
+        _lib.set_option("depth_buckets", 1)
 
 
 @pytest.mark.parametrize("kw", [
@@ -97,7 +99,7 @@ def test_tile_lists_bit_exact(kw, upstream_tile_rule):
     dict(P=30000, width=160, height=112, sh_degree=0, s0=0.02, seed=10, quantize_z=0.001),   # small tie groups: rank path
 ])
 def test_bucketed_depth_order_bit_exact(kw, upstream_tile_rule):
-    """depth_order.hip forced on (it is automatic only for P >= 32768): same sorted pair list as the oracle's one
+    """depth_order.hip forced on for every P (automatic from P = 1024): same sorted pair list as the oracle's one
     stable sort, including exact depth ties (ascending Gaussian id) and degenerate depth distributions."""
     from gaussian_transformer_amd import _lib
     _lib.set_option("depth_buckets", 2)
