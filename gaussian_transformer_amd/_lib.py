@@ -102,3 +102,10 @@ def check(rc: int, what: str) -> None:
 def set_option(name: str, value: int) -> None:
     """Process-wide tuning knob of the native library (include/gsr.h: gsr_set_option)."""
     check(load().gsr_set_option(name.encode(), int(value)), f"gsr_set_option({name})")
+
+
+def get_option(name: str) -> int:
+    """Current value of a tuning knob (include/gsr.h: gsr_get_option)."""
+    v = C.c_int32(0)
+    check(load().gsr_get_option(name.encode(), C.byref(v)), f"gsr_get_option({name})")
+    return int(v.value)

@@ -1,5 +1,8 @@
-// binning.hip -- scan of tiles-touched, (tile, depth) key emission (S7), global radix sort,
-// per-tile range detection (S8).  All HBM-streaming stages.
+// binning.hip -- the rocPRIM-based binning path: depth sort of the Gaussians + scan of tiles-touched, (tile, depth)
+// key emission (S7), radix sort of the pairs, per-tile range detection (S8).  The default path is depth_order.hip +
+// tile_lists.hip; this one runs when those do not apply (a depth bucket beyond LDS capacity, more than 512
+// super-tiles) and under gsr_set_option("depth_buckets" / "tile_lists" / "two_level_sort", 0) as the reference
+// the parity tests compare the fast paths with.
 //
 // Key emission is work-balanced in two levels (rows of the splat rectangles, then output pairs), each a
 // flattened walk with a 6-step ds_bpermute search over a wave-wide scan -- see emit_keys_kernel.
@@ -17,12 +20,6 @@ hipError_t scan_temp_bytes(int P, size_t *bytes) {
                                            (size_t)(P > 0 ? P : 1), rocprim::plus<uint32_t>(), (hipStream_t)0, false);
     *bytes = tb;
     return e;
-}
-
-hipError_t launch_scan(const GeomView &g, int P, hipStream_t s) {
-    size_t tb = g.scan_temp_bytes;
-    return rocprim::inclusive_scan(g.scan_temp, tb, (const uint32_t *)g.tiles, g.offsets, (size_t)P,
-                                   rocprim::plus<uint32_t>(), s, false);
 }
 
 hipError_t sort_temp_bytes(int64_t N, int bits, size_t *bytes) {

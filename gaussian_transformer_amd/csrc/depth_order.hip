@@ -32,11 +32,12 @@ namespace gsr {
 #define DO_RANK_MAX 96                            // largest sub-bucket handled by rank-by-counting
 #define DO_CNT_THREADS 1024                       // counting / scatter workgroups: one uint4 (4 Gaussians) per thread per step
 
-DepthOrderPlan depth_order_plan(int P) {
+DepthOrderPlan depth_order_plan(int P, int log_map) {
     DepthOrderPlan p;
     const long n = P > 0 ? P : 1;
     p.nb = 64;
     while (p.nb < GSR_DO_MAXB && (long)p.nb * 2048 < n) p.nb *= 2;
+    if (log_map) p.nb = p.nb * 4 < GSR_DO_MAXB ? p.nb * 4 : GSR_DO_MAXB;   // outliers leave most buckets empty: more of them
     p.chunk = 4 * DO_CNT_THREADS;
     while ((n + p.chunk - 1) / p.chunk > GSR_DO_MAXBLK) p.chunk *= 2;
     p.nblk = (int)((n + p.chunk - 1) / p.chunk);
@@ -44,16 +45,29 @@ DepthOrderPlan depth_order_plan(int P) {
     return p;
 }
 
-__device__ __forceinline__ float do_scale(uint32_t kmin, uint32_t kmax, uint32_t nfine) {
-    const float dmin = __uint_as_float(kmin), dmax = __uint_as_float(kmax);
-    return (kmax > kmin) ? (float)nfine / (dmax - dmin) : 0.f;
-}
-// monotone non-decreasing in the key (positive floats): subtraction, multiplication by a non-negative
-// constant, truncation and the clamp all preserve order
-__device__ __forceinline__ uint32_t do_fine(uint32_t key, float dmin, float scale, uint32_t nfine) {
-    const float v = (__uint_as_float(key) - dmin) * scale;
-    const uint32_t f = v > 0.f ? (uint32_t)v : 0u;
-    return f < nfine ? f : nfine - 1u;
+// The bucket map: a monotone non-decreasing function of the key (depth bits of a positive float) onto [0, nfine).
+// Linear in DEPTH by default; linear in the depth BITS (logarithmic in depth, exact integer difference first) once a
+// frame has overflowed a bucket -- a few far outliers stretch a linear map until the bulk of the scene shares one
+// bucket.  Subtraction, int->float conversion, multiplication by a non-negative constant, truncation and the clamp
+// all preserve order.
+struct DoMap {
+    uint32_t kmin, nfine;
+    float dmin, scale;
+    int log_map;
+    __device__ __forceinline__ uint32_t fine(uint32_t key) const {
+        const float x = log_map ? (float)(key - kmin) : (__uint_as_float(key) - dmin);
+        const float v = x * scale;
+        const uint32_t f = v > 0.f ? (uint32_t)v : 0u;
+        return f < nfine ? f : nfine - 1u;
+    }
+};
+__device__ __forceinline__ DoMap do_map(uint32_t kmin, uint32_t kmax, uint32_t nfine, int log_map) {
+    DoMap m;
+    m.kmin = kmin; m.nfine = nfine; m.log_map = log_map;
+    m.dmin = __uint_as_float(kmin);
+    const float span = log_map ? (float)(kmax - kmin) : (__uint_as_float(kmax) - m.dmin);
+    m.scale = (kmax > kmin && span > 0.f) ? (float)nfine / span : 0.f;
+    return m;
 }
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
@@ -114,7 +128,7 @@ __global__ __launch_bounds__(256) void do_gather_rect_kernel(int P, const uint32
     orect[r] = tiles[id] > 0u ? rect[id] : make_uint4(0u, 0u, 0u, 0u);
 }
 hipError_t launch_entry_total(const GeomView &g, int P, hipStream_t s) {
-    const DepthOrderPlan pl = depth_order_plan(P);
+    const DepthOrderPlan pl = depth_order_plan(P, 0);
     hipLaunchKernelGGL(do_entry_total_kernel, dim3(1), dim3(1024), 0, s, pl.npre, g.dord.blkent, g.dord.hdr);
     hipLaunchKernelGGL(do_gather_rect_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.perm, g.tiles, g.rect, g.orect);
     return hipGetLastError();
@@ -123,7 +137,7 @@ hipError_t launch_entry_total(const GeomView &g, int P, hipStream_t s) {
 // Level-1 histogram (count, pair-count sum per bucket): LDS per workgroup, then one global atomic per touched
 // bucket.  (A "last workgroup scans the totals" tail needs an agent-scope fence in every workgroup -- an L2
 // write-back per workgroup on this multi-XCD part, 55 us measured -- so the scan is its own one-workgroup launch.)
-__global__ __launch_bounds__(DO_CNT_THREADS) void do_hist_kernel(int P, int chunk, int nb, int npre, const uint32_t *__restrict__ depth,
+__global__ __launch_bounds__(DO_CNT_THREADS) void do_hist_kernel(int P, int chunk, int nb, int npre, int log_map, const uint32_t *__restrict__ depth,
                                                                  const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ blkmin,
                                                                  const uint32_t *__restrict__ blkmax, const uint32_t *__restrict__ blkent,
                                                                  uint32_t *__restrict__ hdr, uint32_t *__restrict__ gcnt,
@@ -142,8 +156,7 @@ __global__ __launch_bounds__(DO_CNT_THREADS) void do_hist_kernel(int P, int chun
     for (int b = threadIdx.x; b < 2 * nb; b += DO_CNT_THREADS) sm[b] = 0u;
     uint32_t kmin, kmax;
     do_key_range(npre, blkmin, blkmax, s_red, kmin, kmax);          // contains a barrier: sm is zeroed for everyone after it
-    const uint32_t nfine = (uint32_t)nb * GSR_DO_NSUB;
-    const float dmin = __uint_as_float(kmin), scale = do_scale(kmin, kmax, nfine);
+    const DoMap map = do_map(kmin, kmax, (uint32_t)nb * GSR_DO_NSUB, log_map);
     if (blockIdx.x == 0 && threadIdx.x == 0) {                         // s_ent is complete: do_key_range has a barrier
         uint32_t e = 0;
         for (int k = 0; k < DO_CNT_THREADS / 64; k++) e += s_ent[k];
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(DO_CNT_THREADS) void do_hist_kernel(int P, int chun
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             if (i + q < i1 && tt[q] > 0u) {
-                const uint32_t b = do_fine(dd[q], dmin, scale, nfine) / GSR_DO_NSUB;
+                const uint32_t b = map.fine(dd[q]) / GSR_DO_NSUB;
                 atomicAdd(&h[b], 1u);
                 atomicAdd(&ts[b], tt[q]);
             }
@@ -210,7 +223,7 @@ __global__ __launch_bounds__(DO_CNT_THREADS) void do_bucket_scan_kernel(int nb, 
 
 // place every emitting Gaussian in its level-1 bucket: the workgroup reserves one run per touched bucket
 // (returning global atomic), arrival order inside the bucket is arbitrary
-__global__ __launch_bounds__(DO_CNT_THREADS) void do_scatter_kernel(int P, int chunk, int nb, const uint32_t *__restrict__ depth,
+__global__ __launch_bounds__(DO_CNT_THREADS) void do_scatter_kernel(int P, int chunk, int nb, int log_map, const uint32_t *__restrict__ depth,
                                                                     const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ hdr,
                                                                     const uint32_t *__restrict__ bstart, uint32_t *__restrict__ gcur,
                                                                     uint64_t *__restrict__ comp) {
@@ -218,8 +231,7 @@ __global__ __launch_bounds__(DO_CNT_THREADS) void do_scatter_kernel(int P, int c
     if (hdr[DO_OVERFLOW]) return;                                  // grid-uniform: the host takes the rocPRIM path
     for (int b = threadIdx.x; b < nb; b += DO_CNT_THREADS) h[b] = 0u;
     __syncthreads();
-    const uint32_t kmin = hdr[DO_KMIN], kmax = hdr[DO_KMAX], nfine = (uint32_t)nb * GSR_DO_NSUB;
-    const float dmin = __uint_as_float(kmin), scale = do_scale(kmin, kmax, nfine);
+    const DoMap map = do_map(hdr[DO_KMIN], hdr[DO_KMAX], (uint32_t)nb * GSR_DO_NSUB, log_map);
     const int i0 = blockIdx.x * chunk, i1 = min(P, i0 + chunk);
     const int steps = chunk / (4 * DO_CNT_THREADS);                // 1 unless P > 2 M
     for (int st = 0; st < steps; st++) {
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(DO_CNT_THREADS) void do_scatter_kernel(int P, int c
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 if (i + q < i1 && tt[q] > 0u) {
-                    const uint32_t b = do_fine(key[q], dmin, scale, nfine) / GSR_DO_NSUB;
+                    const uint32_t b = map.fine(key[q]) / GSR_DO_NSUB;
                     br[q] = b | (atomicAdd(&h[b], 1u) << 12);      // bucket (< 4096) | arrival rank in this step (<= 4096)
                 }
             }
@@ -258,7 +270,7 @@ __global__ __launch_bounds__(DO_CNT_THREADS) void do_scatter_kernel(int P, int c
 
 // one workgroup per level-1 bucket: order its keys in LDS, then scan the pair counts of the ordered slice
 template <bool NEED_OFFSETS>
-__global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, const uint32_t *__restrict__ hdr,
+__global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, int log_map, const uint32_t *__restrict__ hdr,
                                                                         const uint32_t *__restrict__ bstart,
                                                                         const uint32_t *__restrict__ tbase,
                                                                         const uint64_t *__restrict__ comp,
@@ -274,8 +286,7 @@ __global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, 
     const uint32_t s0 = bstart[b];
     const int n = (int)(bstart[b + 1] - s0);
     if (n == 0) return;                                            // workgroup-uniform
-    const uint32_t kmin = hdr[DO_KMIN], kmax = hdr[DO_KMAX], nfine = (uint32_t)nb * GSR_DO_NSUB;
-    const float dmin = __uint_as_float(kmin), scale = do_scale(kmin, kmax, nfine);
+    const DoMap map = do_map(hdr[DO_KMIN], hdr[DO_KMAX], (uint32_t)nb * GSR_DO_NSUB, log_map);
     if (tid <= GSR_DO_NSUB) start[tid] = 0u;
     if (tid == 0) s_max = 0u;
     __syncthreads();
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, 
         const int j = tid + q * DO_SORT_THREADS;
         if (j < n) {
             const uint32_t key = (uint32_t)(comp[s0 + j] >> 32);
-            atomicAdd(&start[do_fine(key, dmin, scale, nfine) & (GSR_DO_NSUB - 1)], 1u);
+            atomicAdd(&start[map.fine(key) & (GSR_DO_NSUB - 1)], 1u);
         }
     }
     __syncthreads();
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, 
         const int j = tid + q * DO_SORT_THREADS;
         if (j < n) {
             const uint64_t c = comp[s0 + j];
-            const uint32_t sub = do_fine((uint32_t)(c >> 32), dmin, scale, nfine) & (GSR_DO_NSUB - 1);
+            const uint32_t sub = map.fine((uint32_t)(c >> 32)) & (GSR_DO_NSUB - 1);
             buf[atomicAdd(&cur[sub], 1u)] = c;                     // arrival order inside the sub-bucket is irrelevant
         }
     }
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, 
             rk[q] = 0u; id[q] = 0u;
             if (j < n) {
                 const uint64_t me = buf[j];
-                const uint32_t sub = do_fine((uint32_t)(me >> 32), dmin, scale, nfine) & (GSR_DO_NSUB - 1);
+                const uint32_t sub = map.fine((uint32_t)(me >> 32)) & (GSR_DO_NSUB - 1);
                 const uint32_t a0 = start[sub], a1 = start[sub + 1];
                 uint32_t r = a0;
                 for (uint32_t k = a0; k < a1; k++) r += buf[k] < me ? 1u : 0u;
@@ -404,17 +415,17 @@ __global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, 
     }
 }
 
-hipError_t launch_depth_order_count(const GeomView &g, int P, uint32_t *host_out, uint32_t seq, hipStream_t s) {
-    const DepthOrderPlan pl = depth_order_plan(P);
+hipError_t launch_depth_order_count(const GeomView &g, int P, int log_map, uint32_t *host_out, uint32_t seq, hipStream_t s) {
+    const DepthOrderPlan pl = depth_order_plan(P, log_map);
     const DepthOrderView &d = g.dord;
-    hipLaunchKernelGGL(do_hist_kernel, dim3(pl.nblk), dim3(DO_CNT_THREADS), 2 * pl.nb * sizeof(uint32_t), s, P, pl.chunk, pl.nb, pl.npre,
+    hipLaunchKernelGGL(do_hist_kernel, dim3(pl.nblk), dim3(DO_CNT_THREADS), 2 * pl.nb * sizeof(uint32_t), s, P, pl.chunk, pl.nb, pl.npre, log_map,
                        reinterpret_cast<const uint32_t *>(g.depth), g.tiles, d.blkmin, d.blkmax, d.blkent, d.hdr, d.gcnt, d.gts);
     hipLaunchKernelGGL(do_bucket_scan_kernel, dim3(1), dim3(DO_CNT_THREADS), 0, s, pl.nb, d.gcnt, d.gts, d.bstart, d.tbase, d.hdr, host_out, seq);
     return hipGetLastError();
 }
 
-hipError_t launch_depth_order_place(const GeomView &g, int P, int need_offsets, hipStream_t s) {
-    const DepthOrderPlan pl = depth_order_plan(P);
+hipError_t launch_depth_order_place(const GeomView &g, int P, int log_map, int need_offsets, hipStream_t s) {
+    const DepthOrderPlan pl = depth_order_plan(P, log_map);
     const DepthOrderView &d = g.dord;
     static bool attr_set = false;   // benign race: the attribute is idempotent
     if (!attr_set) {
@@ -426,13 +437,13 @@ hipError_t launch_depth_order_place(const GeomView &g, int P, int need_offsets, 
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(do_scatter_kernel, dim3(pl.nblk), dim3(DO_CNT_THREADS), pl.nb * sizeof(uint32_t), s, P, pl.chunk, pl.nb,
+    hipLaunchKernelGGL(do_scatter_kernel, dim3(pl.nblk), dim3(DO_CNT_THREADS), pl.nb * sizeof(uint32_t), s, P, pl.chunk, pl.nb, log_map,
                        reinterpret_cast<const uint32_t *>(g.depth), g.tiles, d.hdr, d.bstart, d.gcur, d.comp);
     if (need_offsets)
-        hipLaunchKernelGGL(do_local_sort_kernel<true>, dim3(pl.nb), dim3(DO_SORT_THREADS), GSR_DO_CAP * sizeof(uint64_t), s, pl.nb, d.hdr, d.bstart,
+        hipLaunchKernelGGL(do_local_sort_kernel<true>, dim3(pl.nb), dim3(DO_SORT_THREADS), GSR_DO_CAP * sizeof(uint64_t), s, pl.nb, log_map, d.hdr, d.bstart,
                            d.tbase, d.comp, g.tiles, g.rect, g.perm, g.offsets, g.orect);
     else
-        hipLaunchKernelGGL(do_local_sort_kernel<false>, dim3(pl.nb), dim3(DO_SORT_THREADS), GSR_DO_CAP * sizeof(uint64_t), s, pl.nb, d.hdr, d.bstart,
+        hipLaunchKernelGGL(do_local_sort_kernel<false>, dim3(pl.nb), dim3(DO_SORT_THREADS), GSR_DO_CAP * sizeof(uint64_t), s, pl.nb, log_map, d.hdr, d.bstart,
                            d.tbase, d.comp, g.tiles, g.rect, g.perm, g.offsets, g.orect);
     return hipGetLastError();
 }

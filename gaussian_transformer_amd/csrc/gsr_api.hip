@@ -19,12 +19,13 @@ namespace gsr {
 static thread_local char g_err[512] = "";
 // process-wide (not thread-local): PyTorch's autograd engine calls gsr_backward from its own thread
 static std::atomic<int> g_profiling{0};
-static std::atomic<int> g_exact_cull{1};
-static std::atomic<int> g_bwd_npx{2};
-static std::atomic<int> g_fwd_npx{2};
-static std::atomic<int> g_wpb{1};           // waves per workgroup of the compositing kernels (waves are independent)
-static std::atomic<int> g_two_level_sort{1};   // 1: rocPRIM by tile + per-tile LDS depth sort; 0: one global 64-bit-key sort      // same for the forward compositing kernel      // 8x8 pixel blocks per wave in the reverse compositing kernel (1, 2 or 4)   // output-invariant exact splat-vs-tile culling (gsr_set_option)
+static std::atomic<int> g_exact_cull{1};       // output-invariant exact splat-vs-tile culling
+static std::atomic<int> g_bwd_npx{2};          // 8x8 pixel blocks per wave in the reverse compositing kernel (1, 2 or 4)
+static std::atomic<int> g_fwd_npx{2};          // same for the forward compositing kernel
+static std::atomic<int> g_wpb{1};              // waves per workgroup of the compositing kernels (waves are independent)
+static std::atomic<int> g_two_level_sort{1};   // 1: depth order first, then per-tile lists; 0: one global sort on tile<<32|depth
 static std::atomic<int> g_tile_lists{1};       // 1: tile_lists.hip (super-tile entries); 0: key emission + rocPRIM sort + range detection
+static std::atomic<int> g_depth_log_map{0};    // set once a frame overflowed a depth bucket under the linear map (outliers): log map from then on
 static std::atomic<int> g_depth_buckets{1};    // 0: rocPRIM radix sort + scan; 1: depth_order.hip when P is large enough; 2: always (tests)
 #define GSR_DEPTH_BUCKETS_MIN_P 1024           // measured at P = 10 k: 25 us against 48 us for rocPRIM sort + scan + copy-back
 static float g_stage_ms[GSR_NUM_STAGES] = {0};
@@ -66,11 +67,11 @@ GeomView carve_geom(void *base, int P, size_t scan_tb, size_t dsort_tb) {
     g.scan_temp_bytes = scan_tb;
     g.dsort_temp = take(dsort_tb);
     g.dsort_temp_bytes = dsort_tb;
-    const DepthOrderPlan pl = depth_order_plan(P);
+    const DepthOrderPlan pl = depth_order_plan(P, 0);          // npre; the bucket tables are sized for the maximum
     g.dord.hdr = (uint32_t *)take(GSR_DO_ZERO_WORDS * sizeof(uint32_t));
     g.dord.gcnt = g.dord.hdr + DO_HDR_WORDS; g.dord.gts = g.dord.gcnt + GSR_DO_MAXB; g.dord.gcur = g.dord.gts + GSR_DO_MAXB;
-    g.dord.bstart = (uint32_t *)take((pl.nb + 1) * sizeof(uint32_t));
-    g.dord.tbase = (uint32_t *)take((pl.nb + 1) * sizeof(uint32_t));
+    g.dord.bstart = (uint32_t *)take((GSR_DO_MAXB + 1) * sizeof(uint32_t));
+    g.dord.tbase = (uint32_t *)take((GSR_DO_MAXB + 1) * sizeof(uint32_t));
     g.dord.blkmin = (uint32_t *)take(pl.npre * sizeof(uint32_t));
     g.dord.blkmax = (uint32_t *)take(pl.npre * sizeof(uint32_t));
     g.dord.blkent = (uint32_t *)take(pl.npre * sizeof(uint32_t));
@@ -225,6 +226,7 @@ int32_t gsr_set_option(const char *name, int32_t value) {
     if (name && !strcmp(name, "exact_tile_cull")) { g_exact_cull.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "two_level_sort")) { g_two_level_sort.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "tile_lists")) { g_tile_lists.store(value ? 1 : 0); return GSR_OK; }
+    if (name && !strcmp(name, "depth_log_map")) { g_depth_log_map.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "depth_buckets")) {
         if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARGUMENT, "depth_buckets must be 0, 1 or 2");
         g_depth_buckets.store(value); return GSR_OK;
@@ -249,6 +251,7 @@ int32_t gsr_get_option(const char *name, int32_t *value) {
     if (name && value && !strcmp(name, "fwd_blocks_per_wave")) { *value = g_fwd_npx.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "two_level_sort")) { *value = g_two_level_sort.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "tile_lists")) { *value = g_tile_lists.load(); return GSR_OK; }
+    if (name && value && !strcmp(name, "depth_log_map")) { *value = g_depth_log_map.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "depth_buckets")) { *value = g_depth_buckets.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "composite_waves_per_block")) { *value = g_wpb.load(); return GSR_OK; }
     return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_get_option: unknown option '%s'", name ? name : "(null)");
@@ -348,8 +351,9 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
         ReadbackSlot *sl = debug ? nullptr : acquire_slot();
         const uint32_t seq = sl ? (g_seq.fetch_add(1) | 0x80000000u) : 0u;
         if (sl) sl->host[4] = 0u;
-        hipError_t e = launch_depth_order_count(g, P, sl ? sl->host : nullptr, seq, s);
-        if (e == hipSuccess) e = launch_depth_order_place(g, P, want_tile_lists ? 0 : 1, s);   // runs while the host waits for the totals
+        const int log_map = g_depth_log_map.load();
+        hipError_t e = launch_depth_order_count(g, P, log_map, sl ? sl->host : nullptr, seq, s);
+        if (e == hipSuccess) e = launch_depth_order_place(g, P, log_map, want_tile_lists ? 0 : 1, s);   // runs while the host waits for the totals
         if (e == hipSuccess && want_tile_lists) e = launch_tile_lists_count(g, P, g.dord.hdr, W, H, s);
         if (e != hipSuccess) { release_slot(sl); return fail(GSR_ERR_HIP, "depth order: %s (%d)", hipGetErrorString(e), (int)e); }
         if (debug) HIP_TRY(hipStreamSynchronize(s), "depth order");
@@ -362,7 +366,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
             HIP_TRY(hipStreamSynchronize(s), "read N sync");
         }
         e32 = h[3];
-        if (h[0]) bucketed = false;                   // a bucket exceeds the LDS capacity: general sort below
+        if (h[0]) { bucketed = false; g_depth_log_map.store(1); }   // a bucket exceeds the LDS capacity: general sort below, log map next time
         else { P_list = (int)h[1]; n32 = h[2]; }
     }
     if (!bucketed) {

@@ -28,7 +28,7 @@ static inline int ceil_log2_u32(uint32_t x) { int b = 0; while ((1u << b) < x &&
 enum { DO_KMIN = 0, DO_KMAX = 1, DO_DONE = 2, DO_OVERFLOW = 3, DO_PV = 4, DO_NTOT = 5, DO_ETOT = 6, DO_HDR_WORDS = 16 };
 #define GSR_DO_ZERO_WORDS (DO_HDR_WORDS + 3 * GSR_DO_MAXB)   // hdr | gcnt | gts | gcur, contiguous, zeroed by preprocess
 struct DepthOrderPlan { int nb, nblk, chunk, npre; };
-DepthOrderPlan depth_order_plan(int P);
+DepthOrderPlan depth_order_plan(int P, int log_map);   // log_map: bucket map linear in the depth bits, 4x the buckets
 struct DepthOrderView {
     uint32_t *hdr;           // [DO_HDR_WORDS]; [DO_OVERFLOW, DO_PV, DO_NTOT] are read back by the host
     uint32_t *gcnt, *gts, *gcur; // [GSR_DO_MAXB] bucket sizes, pair-count sums, scatter cursors
@@ -102,14 +102,13 @@ struct PreprocessArgs {
 hipError_t launch_preprocess_fwd(const PreprocessArgs &a, hipStream_t s);
 
 hipError_t scan_temp_bytes(int P, size_t *bytes);
-hipError_t launch_scan(const GeomView &g, int P, hipStream_t s);
 
 hipError_t sort_temp_bytes(int64_t N, int bits, size_t *bytes);
 hipError_t launch_emit_keys(const GeomView &g, const BinningView &b, int P, int W, int H, int exact_cull, int two_level, hipStream_t s);
 // histogram + bucket scan -> hdr totals; host_out (pinned, may be NULL) receives {overflow, Pv, N, E, seq}
-hipError_t launch_depth_order_count(const GeomView &g, int P, uint32_t *host_out, uint32_t seq, hipStream_t s);
+hipError_t launch_depth_order_count(const GeomView &g, int P, int log_map, uint32_t *host_out, uint32_t seq, hipStream_t s);
 // scatter, per-bucket order (+ scan of the pair counts when need_offsets) -> perm, orect, offsets
-hipError_t launch_depth_order_place(const GeomView &g, int P, int need_offsets, hipStream_t s);
+hipError_t launch_depth_order_place(const GeomView &g, int P, int log_map, int need_offsets, hipStream_t s);
 hipError_t sort2_temp_bytes(int64_t N, int tile_bits, size_t *bytes);
 hipError_t launch_sort2_by_tile(const BinningView &b, int64_t N, int tile_bits, hipStream_t s);
 hipError_t depth_sort_temp_bytes(int P, size_t *bytes);

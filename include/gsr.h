@@ -137,6 +137,9 @@ int32_t gsr_debug_read_image_state(gsr_stream_t stream, int32_t W, int32_t H, co
  *        instead of emitting and radix-sorting (tile, Gaussian) pairs; needs two_level_sort = 1 and an image of at
  *        most 512 super-tiles of 128 x 128 pixels, otherwise the sort path runs.  Same per-tile lists; point_list
  *        is then laid out super-tile-major (ranges[] say where each tile's slice is).  Speed only.
+ *   "depth_log_map" (default 0, set by the library itself): the depth buckets are cut linearly in depth (0) or in the
+ *        depth's float bits, i.e. logarithmically, with 4x the buckets (1).  The library switches to 1 after a frame
+ *        overflowed a bucket (far outliers); exposed for tests.
  *   "depth_buckets" (0, 1 or 2; default 1): how the Gaussians are put in depth order.  0 = rocPRIM radix sort
  *        + scan; 1 = the bucketed depth order of csrc/depth_order.hip when P >= 1024 (falls back to 0 by itself
  *        when a depth bucket does not fit in LDS); 2 = bucketed for every P (tests).  Same order.  Speed only.

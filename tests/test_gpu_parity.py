@@ -109,11 +109,46 @@ def test_bucketed_depth_order_bit_exact(kw, upstream_tile_rule):
         _lib.set_option("depth_buckets", 1)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(P=3000, width=160, height=112, sh_degree=0, s0=0.03, seed=0),
+    dict(P=100000, width=320, height=200, sh_degree=0, s0=0.01, seed=6),
+    dict(P=30000, width=160, height=112, sh_degree=0, s0=0.02, seed=9, quantize_z=0.5),
+    dict(P=6000, width=160, height=112, sh_degree=0, s0=0.03, seed=7, zmin=4.0, zmax=4.0),
+])
+def test_depth_order_log_bucket_map_bit_exact(kw, upstream_tile_rule):
+    """The bucket map that is linear in the depth BITS (what the library switches to after an overflow)."""
+    from gaussian_transformer_amd import _lib
+    _lib.set_option("depth_log_map", 1)
+    try:
+        _check_stages_bit_exact(dict(kw), 2)
+    finally:
+        _lib.set_option("depth_log_map", 0)
+
+
+def test_depth_outliers_switch_the_bucket_map(upstream_tile_rule):
+    """A handful of far outliers stretch the linear depth map until the whole scene shares one bucket: that frame takes
+    the rocPRIM path (same lists), the library switches to the log map and the next frame is bucketed again."""
+    from gaussian_transformer_amd import _lib
+    kw = dict(P=60000, width=320, height=200, sh_degree=0, s0=0.01, seed=21, zmin=3.0, zmax=6.0, outliers=20)
+    assert _lib.get_option("depth_log_map") == 0
+    try:
+        _check_stages_bit_exact(dict(kw), 2)
+        assert _lib.get_option("depth_log_map") == 1
+        _check_stages_bit_exact(dict(kw), 2)
+    finally:
+        _lib.set_option("depth_log_map", 0)
+
+
 def _check_stages_bit_exact(kw, two_level):
     qz = kw.pop("quantize_z", None) if "quantize_z" in kw else None
+    nout = kw.pop("outliers", 0) if "outliers" in kw else 0
     sc = synth.make_scene(**kw)
     if qz:
         sc.means3D[:, 2] = np.round(sc.means3D[:, 2] / qz) * qz
+    if nout:                                   # same screen position, 100x - 1000x the depth
+        f = np.logspace(2, 3, nout).astype(np.float32)
+        sc.means3D[:nout] *= f[:, None]
+        sc.scales[:nout] *= f[:, None]
     S = oracle_scene(sc, scale_modifier=1.0)
     f = ref.get("f32").forward(S)
     og, ob, oi = f["state"].geom(), f["state"].binning(), f["state"].image_state()
