@@ -53,7 +53,7 @@ __device__ __forceinline__ float fold16(float a, float b) {
 }
 
 template <int NPX>
-__global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, int nblocks_padded, int exact_cull) {
+__global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, int nblocks_padded, int /*exact_cull*/) {
     constexpr int UNITS_PER_TILE = 4 / NPX;          // waves per tile
     extern __shared__ __align__(16) float4 stage_dyn[];     // per wave: 64 records x 3 float4, then 16 x 64 floats of reduction scratch
     const int T = a.gridx * a.gridy;
@@ -75,7 +75,6 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
     float fx[NPX], fy[NPX], Tr[NPX], acc0[NPX], acc1[NPX], acc2[NPX];
     float d0[NPX], d1[NPX], d2[NPX], tb[NPX];
     int last[NPX];
-    float bxa[NPX], bya[NPX], bxb[NPX], byb[NPX];     // block rectangles (wave-uniform)
     int max_last = 0;
 #pragma unroll
     for (int q = 0; q < NPX; q++) {
@@ -85,8 +84,6 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
         const bool inside = x < a.W && y < a.H;
         const size_t pix = (size_t)(inside ? y : 0) * a.W + (inside ? x : 0);
         fx[q] = (float)x; fy[q] = (float)y;
-        bxa[q] = (float)x0; bya[q] = (float)y0;
-        bxb[q] = (float)min(x0 + 7, a.W - 1); byb[q] = (float)min(y0 + 7, a.H - 1);
         const float Tf = inside ? a.final_T[pix] : 1.f;
         last[q] = inside ? (int)a.n_contrib[pix] : 0;
         d0[q] = inside ? a.dL_dpix[pix] : 0.f;
@@ -124,13 +121,12 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
         if (lane < cnt) {
             const uint32_t g = a.point_list[range.x + base + lane];
             const float4 r0 = rec4[3 * (size_t)g], r1 = rec4[3 * (size_t)g + 1], r2 = rec4[3 * (size_t)g + 2];
-            uint32_t bits = (1u << NPX) - 1u;
-            if (exact_cull && r2.z > 0.f) {     // tau == 0: the forward ran with culling off -> no information
-                const float invA = 1.f / r0.z, invC = 1.f / r1.x;
-                bits = 0u;
+            // blocks this entry can reach (exact ellipse-vs-block test, gsr_device.h), as the forward pass staged them
+            uint32_t bits = 0u;
 #pragma unroll
-                for (int q = 0; q < NPX; q++)
-                    bits |= block_reachable(r0.x, r0.y, r0.z, r0.w, r1.x, invA, invC, r2.z, bxa[q], bxb[q], bya[q], byb[q]) ? (1u << q) : 0u;
+            for (int q = 0; q < NPX; q++) {
+                const int blk = NPX == 4 ? q : (NPX == 2 ? sub * 2 + q : sub);
+                bits |= a.contrib[(size_t)blk * a.contrib_stride + range.x + base + lane] ? (1u << q) : 0u;
             }
             live = bits != 0u;
             my[lane * 3 + 0] = r0; my[lane * 3 + 1] = r1;

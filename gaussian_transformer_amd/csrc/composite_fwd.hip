@@ -82,6 +82,12 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
                     bits |= block_reachable(r0.x, r0.y, r0.z, r0.w, r1.x, invA, invC, r2.z, bxa[q], bxb[q], bya[q], byb[q]) ? (1u << q) : 0u;
             }
             live = bits != 0u;
+            // the reverse pass stages the same entries against the same blocks: hand it the reachability bits
+#pragma unroll
+            for (int q = 0; q < NPX; q++) {
+                const int blk = NPX == 4 ? q : (NPX == 2 ? sub * 2 + q : sub);
+                a.contrib[(size_t)blk * a.contrib_stride + range.x + base + lane] = (uint8_t)((bits >> q) & 1u);
+            }
             // (px, py, -0.5*log2e*A, -log2e*B) (-0.5*log2e*C, opacity, r, g) (b, -, block bits, -)
             r0.z *= -0.5f * LOG2E; r0.w *= -LOG2E; r1.x *= -0.5f * LOG2E;
             my[lane * 3 + 0] = r0; my[lane * 3 + 1] = r1;

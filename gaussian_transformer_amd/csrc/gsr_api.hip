@@ -101,6 +101,7 @@ BinningView carve_binning(void *base, int64_t N, size_t sort_tb) {
     size_t off = 0;
     auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += align_up(bytes); return r; };
     b.point_list = (uint32_t *)take(n * sizeof(uint32_t));
+    b.contrib = (uint8_t *)take(4 * n);
     b.keys_sorted = (uint64_t *)take(n * sizeof(uint64_t));
     b.keys_unsorted = (uint64_t *)take(n * sizeof(uint64_t));
     b.point_list_unsorted = (uint32_t *)take(n * sizeof(uint32_t));
@@ -391,7 +392,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     BinningView b;
     TileListView tv;
     if (tile_lists) {             // point_list first (what backward and the debug reader expect), then the entry workspace
-        const size_t pl_bytes = align_up((size_t)N * sizeof(uint32_t));
+        const size_t pl_bytes = align_up((size_t)N * sizeof(uint32_t)) + align_up(4 * (size_t)N);   // point_list + contrib
         tv = carve_tile_lists(nullptr, tlp, E);
         const size_t total = pl_bytes + tv.total_bytes;
         char *bin_ptr = (char *)binning_alloc(binning_user, total);
@@ -425,6 +426,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     }
     CompositeArgs ca;
     ca.W = W; ca.H = H; ca.gridx = gridx; ca.gridy = gridy; ca.ranges = im.ranges; ca.point_list = b.point_list;
+    ca.contrib = b.contrib; ca.contrib_stride = (size_t)(N > 0 ? N : 1);
     ca.rec = g.rec; ca.bg = bg; ca.final_T = im.final_T; ca.n_contrib = im.n_contrib; ca.out_color = out_color;
     HIP_TRY(launch_composite_fwd(ca, g_fwd_npx.load(), pa.exact_cull, g_wpb.load(), s), "composite launch");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "composite");
@@ -466,7 +468,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     if (geom_bytes < g.total_bytes) return fail(GSR_ERR_WORKSPACE, "geom workspace %zu < %zu", geom_bytes, g.total_bytes);
     if (img_bytes < im.total_bytes) return fail(GSR_ERR_WORKSPACE, "image workspace %zu < %zu", img_bytes, im.total_bytes);
     BinningView b = carve_binning(const_cast<void *>(binning_ws), R, 0);
-    if (R > 0 && binning_bytes < align_up((size_t)R * sizeof(uint32_t)))
+    if (R > 0 && binning_bytes < align_up((size_t)R * sizeof(uint32_t)) + align_up(4 * (size_t)R))
         return fail(GSR_ERR_WORKSPACE, "binning workspace too small for R=%lld", (long long)R);
     const size_t acc_bytes = (size_t)P * GSR_ACC_FLOATS * sizeof(float);
     if (bwd_bytes < acc_bytes) return fail(GSR_ERR_WORKSPACE, "backward workspace %zu < %zu", bwd_bytes, acc_bytes);
@@ -479,6 +481,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     if (R > 0) {
         CompositeBwdArgs ca;
         ca.W = W; ca.H = H; ca.gridx = gridx; ca.gridy = gridy; ca.ranges = im.ranges; ca.point_list = b.point_list;
+        ca.contrib = b.contrib; ca.contrib_stride = (size_t)R;
         ca.rec = g.rec; ca.bg = bg; ca.final_T = im.final_T; ca.n_contrib = im.n_contrib; ca.dL_dpix = dL_dpix;
         ca.acc = (float *)bwd_ws;
         HIP_TRY(launch_composite_bwd(ca, g_bwd_npx.load(), g_exact_cull.load(), g_wpb.load(), s), "composite backward launch");

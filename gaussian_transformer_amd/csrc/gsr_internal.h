@@ -75,6 +75,8 @@ struct BinningView {
     //   two-level    : A point_list (ids sorted by tile, in depth order) | B tile keys unsorted (u32)
     //                  | C ids unsorted (u32) | D tile keys sorted
     uint32_t *point_list;        // [N] sorted Gaussian ids           (read by backward)
+    uint8_t *contrib;            // [4][N] per 8x8 block of the tile: can this list entry reach the block (alpha >= 1/255)?
+                                 //        written by composite_fwd for the entries it staged, read by composite_bwd
     uint64_t *keys_sorted;       // [N]
     uint64_t *keys_unsorted;     // [N]
     uint32_t *point_list_unsorted;  // [N]
@@ -142,6 +144,8 @@ hipError_t launch_ranges(const BinningView &b, const ImageView &im, int64_t N, i
 
 struct CompositeArgs {
     int W, H, gridx, gridy;
+    uint8_t *contrib;            // [4][contrib_stride]
+    size_t contrib_stride;
     const uint2 *ranges;
     const uint32_t *point_list;
     const float *rec;
@@ -154,6 +158,8 @@ hipError_t launch_composite_fwd(const CompositeArgs &a, int npx, int exact_cull,
 
 struct CompositeBwdArgs {
     int W, H, gridx, gridy;
+    const uint8_t *contrib;      // [4][contrib_stride], from the forward pass
+    size_t contrib_stride;
     const uint2 *ranges;
     const uint32_t *point_list;
     const float *rec;
