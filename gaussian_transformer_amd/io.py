@@ -85,9 +85,9 @@ BasicPointCloud = namedtuple("BasicPointCloud", ["points", "colors", "normals"])
 def fetch_point_cloud(path: str) -> BasicPointCloud:
     """scene/dataset_readers.py:107-113: positions, colours / 255, normals."""
     v = read_ply_vertices(path)
-    pos = np.vstack([v["x"], v["y"], v["z"]]).T
-    col = np.vstack([v["red"], v["green"], v["blue"]]).T / 255.0
-    nrm = np.vstack([v["nx"], v["ny"], v["nz"]]).T
+    pos = np.ascontiguousarray(np.vstack([v["x"], v["y"], v["z"]]).T)
+    col = np.ascontiguousarray(np.vstack([v["red"], v["green"], v["blue"]]).T / 255.0)
+    nrm = np.ascontiguousarray(np.vstack([v["nx"], v["ny"], v["nz"]]).T)
     return BasicPointCloud(points=pos, colors=col, normals=nrm)
 
 

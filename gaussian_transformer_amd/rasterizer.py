@@ -33,7 +33,11 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 def _ptr(t: Optional[torch.Tensor]):
-    return None if t is None or t.numel() == 0 else t.data_ptr()
+    if t is None or t.numel() == 0:
+        return None
+    if not t.is_contiguous():      # the C ABI takes dense row-major buffers; the public entry points make them so
+        raise _lib.GsrError(f"non-contiguous tensor of shape {tuple(t.shape)} passed to the native rasterizer")
+    return t.data_ptr()
 
 
 def _f32c(t: torch.Tensor, name: str, device) -> torch.Tensor:

@@ -145,6 +145,9 @@ def main():
     np.savez(os.path.join(a.out, "io_colmap.npz"), cam_id=cam.id, cam_model=cam.model, cam_width=cam.width, cam_height=cam.height,
              cam_params=cam.params, cam2_params=cam2.params, cam2_width=cam2.width, n_points=xyz.shape[0],
              xyz_first=xyz[:K], rgb_first=rgb[:K], err_first=err[:K], bbox_min=xyz.min(0), bbox_max=xyz.max(0))
+    # the whole SfM cloud of table_ds (17 618 points, a data file of the reference's dataset): a realistic depth /
+    # footprint distribution for the GPU parity tests (BASELINE config 2 names this scene)
+    shutil.copyfile(os.path.join(model_dir, "points3D.ply"), os.path.join(a.out, "table_points3D.ply"))
     print("wrote", sorted(os.listdir(a.out)))
 
 

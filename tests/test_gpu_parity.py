@@ -20,7 +20,7 @@ def _stage_dump(S):
     from gaussian_transformer_amd.rasterizer import GaussianRasterizationSettings, get_backend
     be = get_backend()
     dev = "cuda"
-    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev) if a is not None else torch.empty(0, device=dev)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev) if a is not None else torch.empty(0, device=dev)
     P = int(np.asarray(S.means3D).shape[0])
     rs = GaussianRasterizationSettings(S.H, S.W, S.tanfovx, S.tanfovy, t(S.bg), S.scale_modifier,
                                        t(np.asarray(S.viewmatrix).reshape(4, 4)), t(np.asarray(S.projmatrix).reshape(4, 4)),
@@ -243,6 +243,60 @@ def test_forward_backward_parity(case):
         assert grad_err(hg[a], g[b]) < GRAD_RTOL, (a, grad_err(hg[a], g[b]))
     assert grad_err(hg["opacities"].reshape(-1), g["dL_dopacity"]) < GRAD_RTOL
     assert np.all(hg["means2D"][:, 2] == 0)
+
+
+def _table_scene(width=1008, height=567):
+    """The reference's table_ds SfM cloud (tests/golden/table_points3D.ply, 17 618 points) turned into Gaussians the way
+    scene/gaussian_model.py:124-146 initialises them (scale = sqrt of the mean squared distance to the 3 nearest points,
+    identity rotation, opacity 0.1, SH dc from the colour), seen by table_ds's own camera intrinsics (cameras.bin,
+    f = 3049.78 on 4032 x 2268, at 1/4 resolution) from the COLMAP origin.  images.bin (the poses) is not in the snapshot."""
+    import os
+    from scipy.spatial import cKDTree
+    from gaussian_transformer_amd import io as gio
+    pc = gio.fetch_point_cloud(os.path.join(os.path.dirname(__file__), "golden", "table_points3D.ply"))
+    xyz = pc.points.astype(np.float32)
+    d, _ = cKDTree(xyz).query(xyz, k=4)
+    dist2 = np.maximum((d[:, 1:] ** 2).mean(1), 1e-7)
+    P = xyz.shape[0]
+    scales = np.repeat(np.sqrt(dist2)[:, None], 3, axis=1).astype(np.float32)
+    rots = np.zeros((P, 4), np.float32); rots[:, 0] = 1
+    opac = np.full((P, 1), 0.1, np.float32)
+    shs = np.zeros((P, 16, 3), np.float32)
+    shs[:, 0, :] = (pc.colors - 0.5) / 0.28209479177387814
+    cam = synth.identity_camera(width, height, tanfovx=4032.0 / (2.0 * 3049.779011853469))
+    dL = (np.random.default_rng(5).normal(size=(3, height, width)) / (3.0 * height * width)).astype(np.float32)
+    return synth.SyntheticScene(cam, xyz, scales, rots, opac, shs, 3, np.zeros(3, np.float32), dL)
+
+
+def test_table_scene_lists_bit_exact(upstream_tile_rule):
+    """Real SfM depth / footprint distribution through depth_order.hip + tile_lists.hip: same per-tile lists as the oracle."""
+    sc = _table_scene()
+    S = oracle_scene(sc)
+    f = ref.get("f32").forward(S)
+    ob = f["state"].binning()
+    h = _stage_dump(S)
+    np.testing.assert_array_equal(h["radii"], f["radii"])
+    assert (f["radii"] > 0).sum() > 10000 and f["num_rendered"] > 100000      # the cloud is in view (10 726 splats, 116 814 pairs)
+    assert h["n"] == f["num_rendered"]
+    np.testing.assert_array_equal(h["point_list"], ob["vals"])
+    np.testing.assert_array_equal(h["ranges"], ob["ranges"])
+    assert_image_close(h["color"], f["color"])
+
+
+def test_table_scene_forward_backward_parity():
+    sc = _table_scene()
+    S = oracle_scene(sc)
+    dL = np.random.default_rng(6).normal(size=(3, S.H, S.W)).astype(np.float32)
+    r = ref.get("f32")
+    f = r.forward(S); g = r.backward(f, dL)
+    h = hip_forward_backward(S, dL)
+    np.testing.assert_array_equal(h["radii"], f["radii"])
+    assert_image_close(h["color"], f["color"])
+    hg = h["grads"]
+    for a, b in [("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("shs", "dL_dsh"), ("scales", "dL_dscales"),
+                 ("rotations", "dL_drots")]:
+        assert grad_err(hg[a], g[b]) < GRAD_RTOL, (a, grad_err(hg[a], g[b]))
+    assert grad_err(hg["opacities"].reshape(-1), g["dL_dopacity"]) < GRAD_RTOL
 
 
 @pytest.mark.parametrize("npx", [1, 2, 4])
