@@ -63,7 +63,9 @@ const char *gsr_last_error(void);
  *   bwd_bytes  : scratch used only inside gsr_backward (gradient accumulators) */
 int32_t gsr_workspace_sizes(int32_t P, int32_t W, int32_t H, size_t *geom_bytes, size_t *img_bytes, size_t *bwd_bytes);
 
-/* Size of the binning workspace for N (Gaussian,tile) pairs (what the callback is asked for). */
+/* Size of the binning workspace of the SORT path for N (Gaussian,tile) pairs (informational).  gsr_forward asks the
+ * allocator callback for exactly what the path it takes needs: the default tile-list path wants 8 N + 16 E bytes plus
+ * small tables, E = (Gaussian, super-tile) entries, which only the device knows. */
 int32_t gsr_binning_bytes(int64_t N, int32_t W, int32_t H, size_t *bytes);
 
 /* Forward: per-Gaussian projection + SH (S1-S6), scan, key emission (S7), radix sort,
