@@ -145,6 +145,74 @@ def main():
     np.savez(os.path.join(a.out, "io_colmap.npz"), cam_id=cam.id, cam_model=cam.model, cam_width=cam.width, cam_height=cam.height,
              cam_params=cam.params, cam2_params=cam2.params, cam2_width=cam2.width, n_points=xyz.shape[0],
              xyz_first=xyz[:K], rgb_first=rgb[:K], err_first=err[:K], bbox_min=xyz.min(0), bbox_max=xyz.max(0))
+    # ---- density control: the reference's GaussianModel on CPU (scene/gaussian_model.py:149-167, 210-213, 258-407) ----
+    # plyfile is not installed (only needed by its PLY I/O): an empty stand-in module lets the file import; its
+    # simple_knn._C import resolves to this repo's module and is never called here; device="cuda" literals are shimmed.
+    import types
+    sys.modules.setdefault("plyfile", types.SimpleNamespace(PlyData=None, PlyElement=None))
+    sys.path.insert(1, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    _zeros2 = torch.zeros
+
+    def zeros_cpu2(*args, **kw):
+        kw.pop("device", None)
+        return _zeros2(*args, **kw)
+    torch.zeros = zeros_cpu2
+    _empty_cache = torch.cuda.empty_cache
+    torch.cuda.empty_cache = lambda: None
+    try:
+        from scene.gaussian_model import GaussianModel
+        from arguments import OptimizationParams
+        import argparse as _ap
+        opt = OptimizationParams(_ap.ArgumentParser())
+        g = torch.Generator().manual_seed(1234)
+        P, deg = 300, 2
+        M = (deg + 1) ** 2
+        init = dict(xyz=torch.randn(P, 3, generator=g), f_dc=torch.randn(P, 1, 3, generator=g) * 0.5,
+                    f_rest=torch.randn(P, M - 1, 3, generator=g) * 0.1, opacity=torch.randn(P, 1, generator=g) * 2.0,
+                    scaling=torch.randn(P, 3, generator=g) * 0.8 - 2.5, rotation=torch.randn(P, 4, generator=g))
+        gm = GaussianModel(deg)
+        gm._xyz, gm._features_dc, gm._features_rest = (torch.nn.Parameter(init[k].clone()) for k in ("xyz", "f_dc", "f_rest"))
+        gm._opacity, gm._scaling, gm._rotation = (torch.nn.Parameter(init[k].clone()) for k in ("opacity", "scaling", "rotation"))
+        gm.max_radii2D = torch.zeros(P)
+        gm.spatial_lr_scale = 2.5
+        gm.training_setup(opt)
+        names = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+        out = {f"init_{k}": v.numpy() for k, v in init.items()}
+        out["lr_at"] = np.array([gm.xyz_scheduler_args(i) for i in (0, 1, 100, 7000, 30000, 40000)])
+        # two Adam steps with fixed gradients so that the moments are non-trivial
+        grads = [{k: torch.randn(init[k].shape, generator=g) * 0.01 for k in names} for _ in range(2)]
+        for step, gr in enumerate(grads):
+            gm.update_learning_rate(step + 1)
+            for grp in gm.optimizer.param_groups:
+                grp["params"][0].grad = gr[grp["name"]].clone()
+            gm.optimizer.step(); gm.optimizer.zero_grad(set_to_none=True)
+            for k in names:
+                out[f"grad{step}_{k}"] = gr[k].numpy()
+        # densification statistics from three "views"
+        stats = []
+        for v in range(3):
+            vs = torch.zeros(P, 3); vs.grad = torch.randn(P, 3, generator=g) * 0.0005
+            vis = torch.rand(P, generator=g) < 0.7
+            radii = (torch.rand(P, generator=g) * 40).floor()
+            gm.max_radii2D[vis] = torch.max(gm.max_radii2D[vis], radii[vis])
+            gm.add_densification_stats(vs, vis)
+            stats.append((vs.grad.numpy(), vis.numpy(), radii.numpy()))
+        for v, (a_, b_, c_) in enumerate(stats):
+            out[f"view{v}_grad"], out[f"view{v}_vis"], out[f"view{v}_radii"] = a_, b_, c_
+        torch.manual_seed(77)                      # the split samples come from the global generator in the reference
+        gm.densify_and_prune(0.0002, 0.005, 4.0, 20)
+        state = lambda tag: {**{f"{tag}_{k}": getattr(gm, a_).detach().numpy() for k, a_ in
+                               zip(names, ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"))},
+                             **{f"{tag}_m_{grp['name']}": gm.optimizer.state[grp["params"][0]]["exp_avg"].numpy() for grp in gm.optimizer.param_groups},
+                             **{f"{tag}_v_{grp['name']}": gm.optimizer.state[grp["params"][0]]["exp_avg_sq"].numpy() for grp in gm.optimizer.param_groups}}
+        out.update(state("dens"))
+        gm.reset_opacity()
+        out.update(state("reset"))
+        np.savez_compressed(os.path.join(a.out, "densify.npz"), **out)
+    finally:
+        torch.zeros = _zeros2
+        torch.cuda.empty_cache = _empty_cache
+
     # the whole SfM cloud of table_ds (17 618 points, a data file of the reference's dataset): a realistic depth /
     # footprint distribution for the GPU parity tests (BASELINE config 2 names this scene)
     shutil.copyfile(os.path.join(model_dir, "points3D.ply"), os.path.join(a.out, "table_points3D.ply"))

@@ -1,0 +1,85 @@
+"""Density control (gaussian_transformer_amd/densify.py) against what the reference's own GaussianModel
+does on the same inputs (tests/golden/densify.npz, produced by oracle/make_golden.py running
+scene/gaussian_model.py on CPU): learning-rate schedule, Adam moments through clone / split / prune, opacity reset."""
+import os
+
+import numpy as np
+import torch
+
+from gaussian_transformer_amd.densify import GROUPS, DensityController, OptimizationParams, expon_lr, quaternion_to_rotation
+from gaussian_transformer_amd.model import GaussianParams
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+ATTR = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity", "scaling": "_scaling",
+        "rotation": "_rotation"}
+
+
+def _model(d):
+    m = GaussianParams(2)
+    for k in GROUPS:
+        setattr(m, ATTR[k], torch.tensor(d[f"init_{k}"]).requires_grad_(True))
+    return m
+
+
+def _check(ctl, d, tag):
+    for g in ctl.optimizer.param_groups:
+        n = g["name"]
+        p = g["params"][0]
+        assert p is getattr(ctl.model, ATTR[n])
+        np.testing.assert_array_equal(p.detach().numpy(), d[f"{tag}_{n}"])
+        st = ctl.optimizer.state[p]
+        np.testing.assert_array_equal(st["exp_avg"].numpy(), d[f"{tag}_m_{n}"])
+        np.testing.assert_array_equal(st["exp_avg_sq"].numpy(), d[f"{tag}_v_{n}"])
+
+
+def test_density_control_matches_reference_model():
+    d = np.load(os.path.join(G, "densify.npz"))
+    m = _model(d)
+    ctl = DensityController(m, OptimizationParams(), spatial_lr_scale=2.5)
+    np.testing.assert_allclose([ctl._xyz_lr(i) for i in (0, 1, 100, 7000, 30000, 40000)], d["lr_at"], rtol=1e-12)
+    for step in range(2):                                   # two Adam steps with the fixture's gradients
+        ctl.update_learning_rate(step + 1)
+        for g in ctl.optimizer.param_groups:
+            g["params"][0].grad = torch.tensor(d[f"grad{step}_{g['name']}"])
+        ctl.optimizer.step(); ctl.optimizer.zero_grad(set_to_none=True)
+    with torch.no_grad():
+        for v in range(3):                                  # statistics of three views (train.py:115-116)
+            vs = torch.zeros(m._xyz.shape[0], 3); vs.grad = torch.tensor(d[f"view{v}_grad"])
+            ctl.record(vs, torch.tensor(d[f"view{v}_vis"]), torch.tensor(d[f"view{v}_radii"]))
+        torch.manual_seed(77)                               # the reference draws the split samples from the global generator
+        n = ctl.densify_and_prune(0.0002, 0.005, 4.0, 20)
+        assert n["cloned"] > 0 and n["split"] > 0 and n["pruned"] > 0, n
+        _check(ctl, d, "dens")
+        P = m._xyz.shape[0]
+        assert m.xyz_gradient_accum.shape == (P, 1) and m.denom.shape == (P, 1) and m.max_radii2D.shape == (P,)
+        ctl.reset_opacity()
+        _check(ctl, d, "reset")
+        assert float(m.get_opacity.max()) <= 0.01 + 1e-7
+    # the optimiser still steps on the replaced tensors
+    for g in ctl.optimizer.param_groups:
+        g["params"][0].grad = torch.ones_like(g["params"][0])
+    before = m._xyz.detach().clone()
+    ctl.optimizer.step()
+    assert not torch.equal(before, m._xyz.detach())
+
+
+def test_split_is_reproducible_across_ranks_with_a_seeded_generator():
+    """data-parallel ranks must densify identically -> samples from a caller-seeded generator."""
+    d = np.load(os.path.join(G, "densify.npz"))
+    outs = []
+    for _ in range(2):
+        m = _model(d)
+        ctl = DensityController(m, OptimizationParams())
+        with torch.no_grad():
+            m.xyz_gradient_accum += 1.0; m.denom += 1.0     # every Gaussian over the threshold
+            torch.manual_seed(int(torch.randint(0, 1 << 30, (1,))))      # different global RNG state per "rank"
+            ctl.densify_and_prune(0.0002, 0.005, 4.0, None, generator=torch.Generator().manual_seed(5))
+        outs.append(m._xyz.detach().clone())
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_helpers():
+    lr = expon_lr(1e-2, 1e-4, max_steps=100)
+    assert abs(lr(0) - 1e-2) < 1e-15 and abs(lr(100) - 1e-4) < 1e-15 and abs(lr(50) - 1e-3) < 1e-12 and lr(-1) == 0.0
+    c = np.load(os.path.join(G, "cov3d.npz"))                   # quaternion -> rotation pinned by utils/general_utils.py
+    np.testing.assert_allclose(quaternion_to_rotation(torch.tensor(c["quats_raw"])).numpy(), c["rot"], atol=1e-6)
