@@ -21,6 +21,14 @@ _i32 = C.c_int32
 _f = C.c_float
 _sz = C.c_size_t
 
+ADAM_MAX_GROUPS = 16
+
+
+class AdamGroup(C.Structure):          # gsr_adam_group_t of include/gsr_optim.h
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_int64), ("lr", C.c_float), ("step", C.c_int32)]
+
+
 SIGNATURES = {
     "gsr_abi_version": (_i32, []),
     "gsr_last_error": (C.c_char_p, []),
@@ -51,6 +59,7 @@ SIGNATURES = {
     "gsr_l1_ssim_backward": (_i32, [_p, _i32, _i32, _i32, _p, _p, _f, _p, _p, _sz, _p]),
     "gsr_knn_workspace": (_i32, [_i32, C.POINTER(_sz)]),
     "gsr_knn_mean_dist2": (_i32, [_p, _i32, _p, _p, _p, _sz]),
+    "gsr_adam_step": (_i32, [_p, _i32, C.POINTER(AdamGroup), C.c_double, C.c_double, C.c_double]),
     "gsr_set_option": (_i32, [C.c_char_p, _i32]),
     "gsr_get_option": (_i32, [C.c_char_p, C.POINTER(_i32)]),
     "gsr_set_profiling": (_i32, [_i32]),

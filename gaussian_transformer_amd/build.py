@@ -34,6 +34,7 @@ SOURCES = {
     "composite_bwd.hip": ["-munsafe-fp-atomics"],
     "ssim_loss.hip": [],
     "knn.hip": [],
+    "adam.hip": [],
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-result",
           "-fgpu-rdc" if False else "-fno-gpu-rdc"]
@@ -78,6 +79,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     headers.append(os.path.join(HERE, "..", "include", "gsr.h"))
     headers.append(os.path.join(HERE, "..", "include", "gsr_loss.h"))
     headers.append(os.path.join(HERE, "..", "include", "gsr_knn.h"))
+    headers.append(os.path.join(HERE, "..", "include", "gsr_optim.h"))
     headers.append(os.path.abspath(__file__))
     cc = hipcc()
     jobs = []

@@ -12,9 +12,11 @@
 #include "../../include/gsr.h"
 #include "../../include/gsr_knn.h"
 #include "../../include/gsr_loss.h"
+#include "../../include/gsr_optim.h"
 #include "gsr_internal.h"
 
 namespace gsr {
+hipError_t launch_adam(int n_groups, const gsr_adam_group_t *groups, double beta1, double beta2, double eps, hipStream_t s);   // adam.hip
 
 static thread_local char g_err[512] = "";
 // process-wide (not thread-local): PyTorch's autograd engine calls gsr_backward from its own thread
@@ -532,6 +534,20 @@ int32_t gsr_l1_ssim_backward(gsr_stream_t stream, int32_t C, int32_t H, int32_t 
     if (ws_bytes < need) return fail(GSR_ERR_WORKSPACE, "loss workspace %zu < %zu", ws_bytes, need);
     HIP_TRY(launch_l1_ssim_backward(C, H, W, img, gt, lambda_dssim, (const float *)ws, grad_loss, grad_img, (hipStream_t)stream),
             "l1+ssim backward launch");
+    return GSR_OK;
+}
+
+// ---- Adam step over all parameter groups (include/gsr_optim.h) ----
+int32_t gsr_adam_step(gsr_stream_t stream, int32_t n_groups, const gsr_adam_group_t *groups, double beta1, double beta2, double eps) {
+    if (n_groups < 0 || n_groups > GSR_ADAM_MAX_GROUPS || (n_groups > 0 && !groups))
+        return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_adam_step: %d groups (at most %d)", n_groups, GSR_ADAM_MAX_GROUPS);
+    for (int k = 0; k < n_groups; k++) {
+        const gsr_adam_group_t &g = groups[k];
+        if (g.n < 0 || (g.n > 0 && (!g.param || !g.grad || !g.exp_avg || !g.exp_avg_sq)) || g.step < 1)
+            return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_adam_step: group %d: n=%lld step=%d or a NULL buffer", k, (long long)g.n, g.step);
+    }
+    if (!(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0)) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_adam_step: betas");
+    HIP_TRY(launch_adam(n_groups, groups, beta1, beta2, eps, (hipStream_t)stream), "adam launch");
     return GSR_OK;
 }
 

@@ -73,7 +73,8 @@ class DensityController:
     """Owns the Adam optimiser of a GaussianParams and keeps it consistent while Gaussians are cloned, split and pruned."""
 
     def __init__(self, model: GaussianParams, opt: Optional[OptimizationParams] = None, spatial_lr_scale: float = 1.0,
-                 fused_adam: bool = False):
+                 fused_adam: bool = False, adam: str = "torch"):
+        """adam: "torch" (torch.optim.Adam; fused_adam=True for its fused kernels) or "hip" (optim.HipAdam, one launch)."""
         self.model = model
         self.opt = opt or OptimizationParams()
         self.spatial_lr_scale = spatial_lr_scale
@@ -87,7 +88,11 @@ class DensityController:
         for n in GROUPS:           # the optimiser must own leaf tensors it can replace
             setattr(model, _ATTR[n], torch.nn.Parameter(getattr(model, _ATTR[n]).detach().clone().requires_grad_(True)))
         groups = [{"params": [getattr(model, _ATTR[n])], "lr": lrs[n], "name": n} for n in GROUPS]
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, **({"fused": True} if fused_adam else {}))
+        if adam == "hip":
+            from .optim import HipAdam
+            self.optimizer = HipAdam(groups, lr=0.0, eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, **({"fused": True} if fused_adam else {}))
         self._xyz_lr = expon_lr(o.position_lr_init * spatial_lr_scale, o.position_lr_final * spatial_lr_scale,
                                 lr_delay_mult=o.position_lr_delay_mult, max_steps=o.position_lr_max_steps)
 

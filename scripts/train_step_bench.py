@@ -21,7 +21,7 @@ ap.add_argument("--config", default="cfg3_synth_1M_1080p")
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--loss", choices=["fused", "torch"], default="fused", help="fused = HIP L1+SSIM kernel (include/gsr_loss.h); torch = grouped conv2d path")
-ap.add_argument("--adam", choices=["fused", "default"], default="fused")
+ap.add_argument("--adam", choices=["hip", "fused", "default"], default="hip", help="hip = one-launch HIP Adam (include/gsr_optim.h); fused/default = torch.optim.Adam")
 ap.add_argument("--render", choices=["fused", "reference"], default="fused", help="fused = raw parameters into the kernels (render_fused)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -31,8 +31,12 @@ cam = TorchCamera(sc.camera, dev)
 bg = torch.tensor(sc.bg, device=dev)
 gt = torch.rand((3, cam.image_height, cam.image_width), device=dev)
 lrs = [0.00016, 0.0025, 0.0025 / 20.0, 0.05, 0.005, 0.001]          # arguments/__init__.py:74-82
-opt = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(pc.parameters(), lrs)], lr=0.0, eps=1e-15,
-                       **({"fused": True} if a.adam == "fused" else {}))
+groups = [{"params": [p], "lr": lr} for p, lr in zip(pc.parameters(), lrs)]
+if a.adam == "hip":
+    from gaussian_transformer_amd.optim import HipAdam
+    opt = HipAdam(groups, lr=0.0, eps=1e-15)
+else:
+    opt = torch.optim.Adam(groups, lr=0.0, eps=1e-15, **({"fused": True} if a.adam == "fused" else {}))
 training_loss = fused_l1_ssim_loss if a.loss == "fused" else training_loss
 render = render_fused if a.render == "fused" else render
 pipe = PipelineParams()

@@ -41,7 +41,7 @@ def run(iters=600, P=20000, size=256, ncam=8, seed=0, densify_from=100, densify_
     model = GaussianParams.from_synthetic(sc0, dev)
     opt = OptimizationParams(densify_from_iter=densify_from, densification_interval=densify_every, opacity_reset_interval=10 ** 9,
                              densify_until_iter=iters)
-    ctl = DensityController(model, opt, spatial_lr_scale=1.0, fused_adam=True)
+    ctl = DensityController(model, opt, spatial_lr_scale=1.0, adam="hip")
     gen = torch.Generator(device=dev).manual_seed(seed)
 
     def evaluate():

@@ -21,7 +21,7 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     from gaussian_transformer_amd.build import build_hip
     path = build_hip()                      # hipcc cross-compiles for gfx950 without a GPU
     lib = ctypes.CDLL(path)
-    header = open(os.path.join(ROOT, "include", "gsr.h")).read() + open(os.path.join(ROOT, "include", "gsr_loss.h")).read() + open(os.path.join(ROOT, "include", "gsr_knn.h")).read()
+    header = open(os.path.join(ROOT, "include", "gsr.h")).read() + open(os.path.join(ROOT, "include", "gsr_loss.h")).read() + open(os.path.join(ROOT, "include", "gsr_knn.h")).read() + open(os.path.join(ROOT, "include", "gsr_optim.h")).read()
     declared = set(re.findall(r"\b(gsr_[a-z0-9_]+)\s*\(", header)) - {"gsr_alloc_fn"}
     assert {"gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_workspace_sizes", "gsr_binning_bytes",
             "gsr_last_error", "gsr_abi_version"} <= declared
