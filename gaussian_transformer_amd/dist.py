@@ -9,6 +9,8 @@ collective over a flat bucket:
   +  2 floats per Gaussian of per-view densification statistics
        (|dL/dmean2D[:, :2]| * visible, visible)  -- scene/gaussian_model.py:405-407 is per view,
        so the norm is taken before the reduction, not after.
+The screen-space radii (train.py:115) are max-reduced separately (4 bytes per Gaussian), which makes the density
+control of densify.py rank-consistent: same statistics + an identically seeded split generator = same Gaussians.
 One process per GPU (torch.distributed.run); backend "nccl" is RCCL over xGMI on ROCm, "gloo"
 in the CPU tests.  No collective is issued inside the rasterizer itself.
 """
@@ -94,4 +96,11 @@ def data_parallel_step(pc, camera, pipe, bg: torch.Tensor, gt_image: Optional[to
     if getattr(pc, "xyz_gradient_accum", None) is not None:
         pc.xyz_gradient_accum += gnorm_sum[:, None]
         pc.denom += vis_count[:, None]
+    # largest screen-space radius over the views of the batch (train.py:115), so that every rank prunes the same
+    # Gaussians afterwards (densify.py: seed the split generator identically on all ranks)
+    if getattr(pc, "max_radii2D", None) is not None:
+        r = torch.where(vis, radii.to(pc.max_radii2D.dtype), torch.zeros_like(pc.max_radii2D))
+        if world > 1:
+            dist.all_reduce(r, op=dist.ReduceOp.MAX, group=group)
+        pc.max_radii2D = torch.max(pc.max_radii2D, r)
     return {"loss": loss.detach(), "render": image.detach(), "radii": radii, "visibility_filter": vis, "bucket": bucket}

@@ -23,7 +23,7 @@ def _scene_and_cams():
     return sc, cams
 
 
-def _run_step(rank, world, cam_index, sc, cams):
+def _run_step(rank, world, cam_index, sc, cams, densify=False):
     from gaussian_transformer_amd import rasterizer
     from gaussian_transformer_amd.dist import data_parallel_step
     from gaussian_transformer_amd.loss import training_loss
@@ -32,9 +32,18 @@ def _run_step(rank, world, cam_index, sc, cams):
     from tests.oracle_backend import OracleBackend
     rasterizer._set_backend_for_tests(OracleBackend())
     pc = GaussianParams.from_synthetic(sc, "cpu")
+    ctl = None
+    if densify:
+        from gaussian_transformer_amd.densify import DensityController
+        ctl = DensityController(pc)
     gt = torch.tensor(np.random.default_rng(7 + cam_index).uniform(0, 1, size=(3, 48, 64)).astype(np.float32))
     out = data_parallel_step(pc, TorchCamera(cams[cam_index], "cpu"), PipelineParams(), torch.tensor(sc.bg), gt,
                              render, training_loss)
+    if densify:
+        with torch.no_grad():
+            torch.manual_seed(1000 + rank)                  # ranks do NOT share the global RNG state ...
+            n = ctl.densify_and_prune(1e-7, 0.005, 3.0, 20, generator=torch.Generator().manual_seed(42))   # ... only this seed
+        out["densified"] = n
     return pc, out
 
 
@@ -49,6 +58,37 @@ def _worker(rank, world, port, q):
                pc.denom.numpy().copy(), out["bucket"].nbytes))
     finally:
         dist.destroy_process_group()
+
+
+def _worker_densify(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        sc, cams = _scene_and_cams()
+        pc, out = _run_step(rank, world, rank, sc, cams, densify=True)
+        q.put((rank, pc._xyz.detach().numpy().copy(), pc._scaling.detach().numpy().copy(), out["densified"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_densify_identically():
+    """Different cameras per rank, reduced statistics, one shared split seed: both ranks end with the same Gaussians."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_densify, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = {}
+    for _ in range(2):
+        r = q.get(timeout=240); res[r[0]] = r
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    assert res[0][3] == res[1][3] and res[0][3]["cloned"] + res[0][3]["split"] > 0, res[0][3]
+    assert res[0][1].shape[0] != 400
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][2], res[1][2])
 
 
 @pytest.mark.timeout(300)
