@@ -4,9 +4,10 @@
 // Output (same contract as launch_depth_sort + launch_ordered_scan of binning.hip):
 //   perm[0..Pv)     ids of the Pv Gaussians that emit at least one (tile, Gaussian) pair, ordered by
 //                   (depth bits, id) -- the order a stable sort on depth of id-ordered input gives
-//   offsets[0..Pv)  inclusive scan of tiles[perm[.]]
-//   hdr[DO_PV], hdr[DO_NTOT]  Pv and N (total pairs); hdr[DO_OVERFLOW] != 0 -> nothing usable, the caller
-//                   falls back to the rocPRIM path.
+//   offsets[0..Pv)  inclusive scan of tiles[perm[.]]        (only when key emission will run: NEED_OFFSETS)
+//   orect[0..Pv)    rect[perm[.]], the 16-byte rectangle + span records in depth order   (for tile_lists.hip)
+//   hdr[DO_PV], hdr[DO_NTOT], hdr[DO_ETOT]  Pv, N (total pairs) and E (super-tile entries); hdr[DO_OVERFLOW] != 0 ->
+//                   nothing usable, the caller falls back to the rocPRIM path.
 //
 // rocPRIM's onesweep needs 4 digit passes + histogram + scan + 4 fills (~165 us for 1 M Gaussians, almost all
 // of it launch latency and decoupled-lookback chains over 8 MB of data).  Here: the depth range is cut into
@@ -16,7 +17,7 @@
 // a second, finer counting split (GSR_DO_NSUB sub-buckets) and a rank-by-counting inside each sub-bucket on the
 // full 64-bit (depth bits, id) key, so the result does not depend on arrival order.  A bucket whose keys pile
 // up in one sub-bucket (coplanar splats) is sorted by an in-LDS bitonic network instead: bounded time for any
-// input.  The same workgroup then scans the pair counts of its sorted slice.
+// input.  The same workgroup then scans the pair counts of its sorted slice (or just carries the records along).
 // Every kernel here is latency-bound (8 MB of keys): the design minimises dependent memory round trips and
 // launches -- preprocess leaves per-workgroup depth extrema, so the whole stage is four launches, and the
 // totals the host needs reach it through pinned memory while the last two kernels run.
