@@ -139,10 +139,52 @@ def test_depth_outliers_switch_the_bucket_map(upstream_tile_rule):
         _lib.set_option("depth_log_map", 0)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(P=1, width=64, height=48, sh_degree=0, s0=0.3, seed=31),                         # one splat
+    dict(P=40, width=17, height=9, sh_degree=0, s0=0.2, seed=32),                         # one ragged tile, one super-tile
+    dict(P=5000, width=3840, height=2160, sh_degree=0, s0=0.01, seed=33, giants=3),       # 510 super-tiles; splats over all of them
+    dict(P=2000, width=1920, height=1080, sh_degree=0, s0=0.2, seed=34),                  # every rectangle beyond 8 x 15 tiles
+])
+def test_tile_list_edge_cases_bit_exact(kw, upstream_tile_rule):
+    """Forced through depth_order.hip + tile_lists.hip whatever P is: degenerate sizes, and rectangles too large for the
+    packed row spans (the level-1 placement then evaluates the ellipse itself, one lane walking hundreds of super-tiles)."""
+    from gaussian_transformer_amd import _lib
+    _lib.set_option("depth_buckets", 2)
+    try:
+        _check_stages_bit_exact(dict(kw), 2)
+    finally:
+        _lib.set_option("depth_buckets", 1)
+
+
+def test_tile_list_edge_cases_with_exact_culling():
+    """Same degenerate scenes in the default mode (exact culling on): image against the oracle, N never above the upstream count."""
+    from gaussian_transformer_amd import _lib
+    _lib.set_option("depth_buckets", 2)
+    try:
+        for kw in (dict(P=1, width=64, height=48, sh_degree=0, s0=0.3, seed=31), dict(P=40, width=17, height=9, sh_degree=0, s0=0.2, seed=32),
+                   dict(P=5000, width=3840, height=2160, sh_degree=0, s0=0.01, seed=33, giants=3)):
+            kw = dict(kw)
+            ng = kw.pop("giants", 0)
+            sc = synth.make_scene(**kw)
+            if ng:
+                sc.scales[:ng] = np.array([8.0, 5.0, 0.5], np.float32)
+            S = oracle_scene(sc)
+            f = ref.get("f32").forward(S)
+            h = _stage_dump(S)
+            np.testing.assert_array_equal(h["radii"], f["radii"])
+            assert h["n"] <= f["num_rendered"]
+            assert_image_close(h["color"], f["color"])
+    finally:
+        _lib.set_option("depth_buckets", 1)
+
+
 def _check_stages_bit_exact(kw, two_level):
     qz = kw.pop("quantize_z", None) if "quantize_z" in kw else None
     nout = kw.pop("outliers", 0) if "outliers" in kw else 0
+    ng = kw.pop("giants", 0) if "giants" in kw else 0
     sc = synth.make_scene(**kw)
+    if ng:                                     # a few splats as large as the whole view
+        sc.scales[:ng] = np.array([8.0, 5.0, 0.5], np.float32)
     if qz:
         sc.means3D[:, 2] = np.round(sc.means3D[:, 2] / qz) * qz
     if nout:                                   # same screen position, 100x - 1000x the depth
