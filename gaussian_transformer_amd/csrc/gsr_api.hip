@@ -27,6 +27,7 @@ static std::atomic<int> g_fwd_npx{2};          // same for the forward compositi
 static std::atomic<int> g_wpb{1};              // waves per workgroup of the compositing kernels (waves are independent)
 static std::atomic<int> g_two_level_sort{1};   // 1: depth order first, then per-tile lists; 0: one global sort on tile<<32|depth
 static std::atomic<int> g_tile_lists{1};       // 1: tile_lists.hip (super-tile entries); 0: key emission + rocPRIM sort + range detection
+static std::atomic<int> g_bucket_fail_p{0x7fffffff};   // smallest P whose buckets overflowed even under the log map: not tried again
 static std::atomic<int> g_depth_log_map{0};    // set once a frame overflowed a depth bucket under the linear map (outliers): log map from then on
 static std::atomic<int> g_depth_buckets{1};    // 0: rocPRIM radix sort + scan; 1: depth_order.hip when P is large enough; 2: always (tests)
 #define GSR_DEPTH_BUCKETS_MIN_P 1024           // measured at P = 10 k: 25 us against 48 us for rocPRIM sort + scan + copy-back
@@ -229,7 +230,7 @@ int32_t gsr_set_option(const char *name, int32_t value) {
     if (name && !strcmp(name, "exact_tile_cull")) { g_exact_cull.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "two_level_sort")) { g_two_level_sort.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "tile_lists")) { g_tile_lists.store(value ? 1 : 0); return GSR_OK; }
-    if (name && !strcmp(name, "depth_log_map")) { g_depth_log_map.store(value ? 1 : 0); return GSR_OK; }
+    if (name && !strcmp(name, "depth_log_map")) { g_depth_log_map.store(value ? 1 : 0); g_bucket_fail_p.store(0x7fffffff); return GSR_OK; }
     if (name && !strcmp(name, "depth_buckets")) {
         if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARGUMENT, "depth_buckets must be 0, 1 or 2");
         g_depth_buckets.store(value); return GSR_OK;
@@ -348,7 +349,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     const bool want_tile_lists = g_tile_lists.load() != 0 && two_level && tile_list_plan(P, 0, W, H).S <= GSR_TL_MAX_S;
     int P_list = P;                                   // entries of the depth-ordered list (perm / offsets)
     const int dbopt = g_depth_buckets.load();
-    bool bucketed = dbopt == 2 || (dbopt == 1 && P >= GSR_DEPTH_BUCKETS_MIN_P);
+    bool bucketed = dbopt == 2 || (dbopt == 1 && P >= GSR_DEPTH_BUCKETS_MIN_P && P < g_bucket_fail_p.load());
     if (bucketed) {
         uint32_t h[4] = {1u, 0u, 0u, 0u};
         ReadbackSlot *sl = debug ? nullptr : acquire_slot();
@@ -369,7 +370,14 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
             HIP_TRY(hipStreamSynchronize(s), "read N sync");
         }
         e32 = h[3];
-        if (h[0]) { bucketed = false; g_depth_log_map.store(1); }   // a bucket exceeds the LDS capacity: general sort below, log map next time
+        if (h[0]) {               // a bucket exceeds the LDS capacity: general sort below, log map next time
+            bucketed = false;
+            if (log_map) {        // already the robust map: stop paying for the attempt at this size
+                int cur = g_bucket_fail_p.load();
+                while (P < cur && !g_bucket_fail_p.compare_exchange_weak(cur, P)) {}
+            }
+            g_depth_log_map.store(1);
+        }
         else { P_list = (int)h[1]; n32 = h[2]; }
     }
     if (!bucketed) {

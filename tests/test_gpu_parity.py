@@ -107,6 +107,7 @@ def test_bucketed_depth_order_bit_exact(kw, upstream_tile_rule):
         _check_stages_bit_exact(dict(kw), 1)
     finally:
         _lib.set_option("depth_buckets", 1)
+        _lib.set_option("depth_log_map", 0)        # an overflowing case switches the process to the log map: undo
 
 
 @pytest.mark.parametrize("kw", [
