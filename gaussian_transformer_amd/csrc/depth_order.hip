@@ -31,13 +31,14 @@ namespace gsr {
 #define DO_SORT_THREADS 1024
 #define DO_ITEMS (GSR_DO_CAP / DO_SORT_THREADS)   // 8 register-resident items per thread
 #define DO_RANK_MAX 96                            // largest sub-bucket handled by rank-by-counting
+#define DO_SCAN_PER (GSR_DO_MAXB / 1024)          // buckets per thread of the one-workgroup bucket scan
 #define DO_CNT_THREADS 1024                       // counting / scatter workgroups: one uint4 (4 Gaussians) per thread per step
 
 DepthOrderPlan depth_order_plan(int P, int log_map) {
     DepthOrderPlan p;
     const long n = P > 0 ? P : 1;
     p.nb = 64;
-    while (p.nb < GSR_DO_MAXB && (long)p.nb * 2048 < n) p.nb *= 2;
+    while (p.nb < GSR_DO_MAXB / 4 && (long)p.nb * 2048 < n) p.nb *= 2;      // more buckets cost more global atomics
     if (log_map) p.nb = p.nb * 4 < GSR_DO_MAXB ? p.nb * 4 : GSR_DO_MAXB;   // outliers leave most buckets empty: more of them
     p.chunk = 4 * DO_CNT_THREADS;
     while ((n + p.chunk - 1) / p.chunk > GSR_DO_MAXBLK) p.chunk *= 2;
@@ -141,8 +142,7 @@ hipError_t launch_entry_total(const GeomView &g, int P, hipStream_t s) {
 __global__ __launch_bounds__(DO_CNT_THREADS) void do_hist_kernel(int P, int chunk, int nb, int npre, int log_map, const uint32_t *__restrict__ depth,
                                                                  const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ blkmin,
                                                                  const uint32_t *__restrict__ blkmax, const uint32_t *__restrict__ blkent,
-                                                                 uint32_t *__restrict__ hdr, uint32_t *__restrict__ gcnt,
-                                                                 uint32_t *__restrict__ gts) {
+                                                                 uint32_t *__restrict__ hdr, unsigned long long *__restrict__ gpair) {
     extern __shared__ uint32_t sm[];
     __shared__ uint32_t s_red[32];
     __shared__ uint32_t s_ent[16];
@@ -180,37 +180,48 @@ __global__ __launch_bounds__(DO_CNT_THREADS) void do_hist_kernel(int P, int chun
     __syncthreads();
     for (int b = threadIdx.x; b < nb; b += DO_CNT_THREADS) {
         const uint32_t c = h[b];
-        if (c) { atomicAdd(&gcnt[b], c); atomicAdd(&gts[b], ts[b]); }
+        if (c) atomicAdd(&gpair[b], (unsigned long long)c | ((unsigned long long)ts[b] << 32));   // count | pair-count sum: one request
     }
 }
 
 // one workgroup: bucket starts, pair-count bases, Pv, N, overflow flag; the totals also go straight to the
 // caller's pinned host words (host_out may be NULL), sequence number last
-__global__ __launch_bounds__(DO_CNT_THREADS) void do_bucket_scan_kernel(int nb, const uint32_t *__restrict__ gcnt,
-                                                                        const uint32_t *__restrict__ gts, uint32_t *__restrict__ bstart,
+__global__ __launch_bounds__(DO_CNT_THREADS) void do_bucket_scan_kernel(int nb, const unsigned long long *__restrict__ gpair,
+                                                                        uint32_t *__restrict__ bstart,
                                                                         uint32_t *__restrict__ tbase, uint32_t *__restrict__ hdr,
                                                                         uint32_t *host_out, uint32_t seq) {
     __shared__ uint32_t wtot[2][16];
     __shared__ uint32_t s_over;
     if (threadIdx.x == 0) s_over = 0u;
     __syncthreads();
-    // thread t owns buckets 2t, 2t+1 (nb <= GSR_DO_MAXB = 2 * DO_CNT_THREADS)
-    const int b0 = 2 * (int)threadIdx.x;
-    uint32_t c0 = 0, c1 = 0, t0 = 0, t1 = 0;
-    if (b0 < nb) { c0 = gcnt[b0]; t0 = gts[b0]; c1 = gcnt[b0 + 1]; t1 = gts[b0 + 1]; }
-    const uint32_t sumc = c0 + c1, sumt = t0 + t1;
+    // thread t owns the DO_SCAN_PER consecutive buckets from t * DO_SCAN_PER (nb <= GSR_DO_MAXB = DO_SCAN_PER * DO_CNT_THREADS)
+    const int b0 = DO_SCAN_PER * (int)threadIdx.x;
+    uint32_t c[DO_SCAN_PER], t[DO_SCAN_PER];
+    uint32_t sumc = 0, sumt = 0;
+    bool over = false;
+#pragma unroll
+    for (int q = 0; q < DO_SCAN_PER; q++) {
+        c[q] = 0u; t[q] = 0u;
+        if (b0 + q < nb) { const unsigned long long pr = gpair[b0 + q]; c[q] = (uint32_t)pr; t[q] = (uint32_t)(pr >> 32); }
+        sumc += c[q]; sumt += t[q];
+        over = over || c[q] > GSR_DO_CAP;
+    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t ic = wave_incl_scan_u32(sumc, lane), it = wave_incl_scan_u32(sumt, lane);
     if (lane == 63) { wtot[0][w] = ic; wtot[1][w] = it; }
-    if (c0 > GSR_DO_CAP || c1 > GSR_DO_CAP) atomicOr(&s_over, 1u);
+    if (over) atomicOr(&s_over, 1u);
     __syncthreads();
     uint32_t ec = ic - sumc, et = it - sumt;
     for (int k = 0; k < w; k++) { ec += wtot[0][k]; et += wtot[1][k]; }
-    if (b0 < nb) {
-        bstart[b0] = ec; tbase[b0] = et;
-        bstart[b0 + 1] = ec + c0; tbase[b0 + 1] = et + t0;
+    {
+        uint32_t rc = ec, rt = et;
+#pragma unroll
+        for (int q = 0; q < DO_SCAN_PER; q++) {
+            if (b0 + q < nb) { bstart[b0 + q] = rc; tbase[b0 + q] = rt; }
+            rc += c[q]; rt += t[q];
+        }
     }
-    if (threadIdx.x == DO_CNT_THREADS - 1) {                       // owns nothing or the last pair: ec + sumc is the total
+    if (threadIdx.x == DO_CNT_THREADS - 1) {                       // owns nothing or the last buckets: ec + sumc is the total
         const uint32_t pv = ec + sumc, ntot = et + sumt, over = s_over;
         bstart[nb] = pv; tbase[nb] = ntot;
         hdr[DO_PV] = pv; hdr[DO_NTOT] = ntot; hdr[DO_OVERFLOW] = over;
@@ -248,7 +259,7 @@ __global__ __launch_bounds__(DO_CNT_THREADS) void do_scatter_kernel(int P, int c
             for (int q = 0; q < 4; q++) {
                 if (i + q < i1 && tt[q] > 0u) {
                     const uint32_t b = map.fine(key[q]) / GSR_DO_NSUB;
-                    br[q] = b | (atomicAdd(&h[b], 1u) << 12);      // bucket (< 4096) | arrival rank in this step (<= 4096)
+                    br[q] = b | (atomicAdd(&h[b], 1u) << 13);      // bucket (< 8192) | arrival rank in this step (<= 4096)
                 }
             }
         }
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(DO_CNT_THREADS) void do_scatter_kernel(int P, int c
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 4; q++)
-            if (br[q] != ~0u) comp[h[br[q] & 0xfffu] + (br[q] >> 12)] = ((uint64_t)key[q] << 32) | (uint32_t)(i + q);
+            if (br[q] != ~0u) comp[h[br[q] & 0x1fffu] + (br[q] >> 13)] = ((uint64_t)key[q] << 32) | (uint32_t)(i + q);
         __syncthreads();
         if (st + 1 < steps) {
             for (int b = threadIdx.x; b < nb; b += DO_CNT_THREADS) h[b] = 0u;
@@ -419,9 +430,18 @@ __global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, 
 hipError_t launch_depth_order_count(const GeomView &g, int P, int log_map, uint32_t *host_out, uint32_t seq, hipStream_t s) {
     const DepthOrderPlan pl = depth_order_plan(P, log_map);
     const DepthOrderView &d = g.dord;
+    static bool attr_set = false;   // benign race: the attribute is idempotent
+    if (!attr_set && 2 * pl.nb * sizeof(uint32_t) > 48 * 1024) {
+        // only the largest bucket counts need it (2 x 8192 counters = 64 KB next to a few static words); raising the
+        // limit when it is not needed costs the kernel ~4 us (measured), so it is set on first use
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(do_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           2 * GSR_DO_MAXB * (int)sizeof(uint32_t));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
     hipLaunchKernelGGL(do_hist_kernel, dim3(pl.nblk), dim3(DO_CNT_THREADS), 2 * pl.nb * sizeof(uint32_t), s, P, pl.chunk, pl.nb, pl.npre, log_map,
-                       reinterpret_cast<const uint32_t *>(g.depth), g.tiles, d.blkmin, d.blkmax, d.blkent, d.hdr, d.gcnt, d.gts);
-    hipLaunchKernelGGL(do_bucket_scan_kernel, dim3(1), dim3(DO_CNT_THREADS), 0, s, pl.nb, d.gcnt, d.gts, d.bstart, d.tbase, d.hdr, host_out, seq);
+                       reinterpret_cast<const uint32_t *>(g.depth), g.tiles, d.blkmin, d.blkmax, d.blkent, d.hdr, d.gpair);
+    hipLaunchKernelGGL(do_bucket_scan_kernel, dim3(1), dim3(DO_CNT_THREADS), 0, s, pl.nb, d.gpair, d.bstart, d.tbase, d.hdr, host_out, seq);
     return hipGetLastError();
 }
 

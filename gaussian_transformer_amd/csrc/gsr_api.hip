@@ -72,7 +72,8 @@ GeomView carve_geom(void *base, int P, size_t scan_tb, size_t dsort_tb) {
     g.dsort_temp_bytes = dsort_tb;
     const DepthOrderPlan pl = depth_order_plan(P, 0);          // npre; the bucket tables are sized for the maximum
     g.dord.hdr = (uint32_t *)take(GSR_DO_ZERO_WORDS * sizeof(uint32_t));
-    g.dord.gcnt = g.dord.hdr + DO_HDR_WORDS; g.dord.gts = g.dord.gcnt + GSR_DO_MAXB; g.dord.gcur = g.dord.gts + GSR_DO_MAXB;
+    g.dord.gpair = reinterpret_cast<unsigned long long *>(g.dord.hdr + DO_HDR_WORDS);     // DO_HDR_WORDS is even: 8-byte aligned
+    g.dord.gcur = g.dord.hdr + DO_HDR_WORDS + 2 * GSR_DO_MAXB;
     g.dord.bstart = (uint32_t *)take((GSR_DO_MAXB + 1) * sizeof(uint32_t));
     g.dord.tbase = (uint32_t *)take((GSR_DO_MAXB + 1) * sizeof(uint32_t));
     g.dord.blkmin = (uint32_t *)take(pl.npre * sizeof(uint32_t));

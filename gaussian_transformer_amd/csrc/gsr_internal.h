@@ -23,15 +23,16 @@ static inline int ceil_log2_u32(uint32_t x) { int b = 0; while ((1u << b) < x &&
 // ---- depth_order.hip: bucketed depth order (replaces the rocPRIM depth sort + ordered scan) ----
 #define GSR_DO_CAP 8192      // largest level-1 bucket one workgroup orders in LDS (64 KB of 64-bit keys)
 #define GSR_DO_NSUB 512      // level-2 sub-buckets per bucket
-#define GSR_DO_MAXB 2048     // level-1 buckets, at most
+#define GSR_DO_MAXB 8192     // level-1 buckets, at most (64 KB of LDS counters in the counting kernel)
 #define GSR_DO_MAXBLK 512    // counting / scatter workgroups, at most
 enum { DO_KMIN = 0, DO_KMAX = 1, DO_DONE = 2, DO_OVERFLOW = 3, DO_PV = 4, DO_NTOT = 5, DO_ETOT = 6, DO_HDR_WORDS = 16 };
-#define GSR_DO_ZERO_WORDS (DO_HDR_WORDS + 3 * GSR_DO_MAXB)   // hdr | gcnt | gts | gcur, contiguous, zeroed by preprocess
+#define GSR_DO_ZERO_WORDS (DO_HDR_WORDS + 3 * GSR_DO_MAXB)   // hdr | gpair (2 words each) | gcur, contiguous, zeroed by preprocess
 struct DepthOrderPlan { int nb, nblk, chunk, npre; };
 DepthOrderPlan depth_order_plan(int P, int log_map);   // log_map: bucket map linear in the depth bits, 4x the buckets
 struct DepthOrderView {
     uint32_t *hdr;           // [DO_HDR_WORDS]; [DO_OVERFLOW, DO_PV, DO_NTOT] are read back by the host
-    uint32_t *gcnt, *gts, *gcur; // [GSR_DO_MAXB] bucket sizes, pair-count sums, scatter cursors
+    unsigned long long *gpair;   // [GSR_DO_MAXB] bucket size | pair-count sum << 32: one 64-bit atomic per workgroup and bucket
+    uint32_t *gcur;              // [GSR_DO_MAXB] scatter cursors
     uint32_t *bstart, *tbase;    // [nb + 1] first position / pair-count base of every bucket
     uint32_t *blkmin, *blkmax;   // [npre] depth-bit extrema of the emitting Gaussians of every preprocess workgroup
     uint32_t *blkent;            // [npre] super-tile entries (tile_lists.hip) of every preprocess workgroup
