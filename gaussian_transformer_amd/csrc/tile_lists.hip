@@ -15,7 +15,7 @@
 //            of the lower lanes in its mask -- deterministic, in depth order, no sort.  The entry carries the
 //            Gaussian id and its 64-bit tile mask, assembled from the row spans preprocess left in one word per
 //            Gaussian (rectangles beyond 8 x 15 tiles re-evaluate the ellipse-vs-tile-row spans here).
-//   level 2  every 256-entry segment of a super-tile's list is expanded by one wave: a 64 x 64 bit-matrix
+//   level 2  every 128-entry segment of a super-tile's list is expanded by one wave: a 64 x 64 bit-matrix
 //            transpose across the wave turns 64 entry masks into 64 tile columns (lane = tile), giving per-segment
 //            tile counts, a column scan per super-tile, then each lane appends the ids of its column's set bits.
 // All of it streams ~16 bytes per entry and 4 bytes per pair.
@@ -30,7 +30,7 @@ namespace gsr {
 #define TL_L1_THREADS GSR_TL_L1
 #define TL_L1_WAVES (TL_L1_THREADS / 64)
 #define TL_SEG GSR_TL_SEG
-#define TL_STAGE 2048             // ids one wave stages in LDS before writing them out (a 256-entry segment yields ~1300)
+#define TL_STAGE 1024             // ids one wave stages in LDS before writing them out (a 128-entry segment yields ~650)
 
 TileListPlan tile_list_plan(int P, int64_t E, int W, int H) {
     TileListPlan p;
