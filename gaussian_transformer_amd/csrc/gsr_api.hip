@@ -181,6 +181,7 @@ static bool wait_seq(const ReadbackSlot *sl, uint32_t seq) {
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (uint32_t spin = 1;; spin++) {
         if (__atomic_load_n(&sl->host[4], __ATOMIC_ACQUIRE) == seq) return true;
+        __builtin_ia32_pause();
         if ((spin & 0xfffffu) == 0) {
             clock_gettime(CLOCK_MONOTONIC, &t1);
             if (t1.tv_sec - t0.tv_sec > 2) return false;
