@@ -118,7 +118,14 @@ def main():
         if world > 1:
             with gradient_arena(flat):
                 grads = torch.autograd.grad(color, params, grad_outputs=dL)
-            dist.all_reduce(flat)
+            if os.environ.get("GSR_ALLREDUCE", "rccl") == "direct":      # two direct exchanges instead of RCCL's all-reduce (dist.py)
+                from gaussian_transformer_amd.dist import direct_all_reduce
+                state["scratch"] = state.get("scratch")
+                if state["scratch"] is None:
+                    state["scratch"] = torch.empty(((world - 1) * ((flat.numel() + world - 1) // world),), dtype=flat.dtype, device=dev)
+                direct_all_reduce(flat, scratch=state["scratch"])
+            else:
+                dist.all_reduce(flat)
         else:
             grads = torch.autograd.grad(color, params, grad_outputs=dL)
         state["color"], state["grads"] = color, grads

@@ -22,6 +22,50 @@ import torch
 import torch.distributed as dist
 
 
+def direct_all_reduce(flat: torch.Tensor, group=None, scratch: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Sum `flat` over the ranks with two direct exchanges instead of a ring: every rank owns one 1/n slice,
+    receives that slice from each peer at once (n-1 point-to-point transfers, one per xGMI link), sums, and sends the
+    reduced slice back to every peer.  Per link and phase S/n bytes, against 2(n-1)/n S through the slowest link of a ring.
+    Point-to-point only (batch_isend_irecv), so it also runs on gloo.  In place; returns `flat`.
+    Not the default of bench.py: which of the two is faster on an 8-GPU node has not been measured (one GPU per box here)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return flat
+    rank = dist.get_rank(group)
+    n = flat.numel()
+    per = (n + world - 1) // world
+    lo = lambda r: min(r * per, n)
+    hi = lambda r: min((r + 1) * per, n)
+    mine = flat[lo(rank):hi(rank)]
+    if scratch is None or scratch.numel() < (world - 1) * per or scratch.device != flat.device:
+        scratch = torch.empty(((world - 1) * per,), dtype=flat.dtype, device=flat.device)
+    peers = [r for r in range(world) if r != rank]
+    to_global = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    # phase 1: my slice of everyone's buffer comes to me
+    ops, bufs = [], []
+    for k, r in enumerate(peers):
+        buf = scratch[k * per:k * per + mine.numel()]
+        bufs.append(buf)
+        if mine.numel():
+            ops.append(dist.P2POp(dist.irecv, buf, to_global(r), group))
+        if hi(r) > lo(r):
+            ops.append(dist.P2POp(dist.isend, flat[lo(r):hi(r)], to_global(r), group))
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    for buf in bufs:
+        mine += buf
+    # phase 2: the reduced slices go back to everyone
+    ops = []
+    for r in peers:
+        if hi(r) > lo(r):
+            ops.append(dist.P2POp(dist.irecv, flat[lo(r):hi(r)], to_global(r), group))
+        if mine.numel():
+            ops.append(dist.P2POp(dist.isend, mine, to_global(r), group))
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    return flat
+
+
 class GradientBucket:
     """Flat, reusable float32 buffer holding every parameter gradient + the densification stats."""
 

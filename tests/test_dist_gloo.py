@@ -60,6 +60,38 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _worker_direct(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gaussian_transformer_amd.dist import direct_all_reduce
+        out = []
+        for n in (1000, 7, 2, 4099):                      # slices that divide evenly, ragged, and ranks that own nothing
+            x = torch.arange(n, dtype=torch.float32) * (rank + 1) + rank
+            ref = x.clone(); dist.all_reduce(ref)
+            got = direct_all_reduce(x.clone())
+            out.append((got.numpy().copy(), ref.numpy().copy()))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_direct_all_reduce_matches_all_reduce(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_direct, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    for rank, out in res:
+        for got, ref in out:
+            np.testing.assert_allclose(got, ref, rtol=1e-6, atol=0)
+
+
 def _worker_densify(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
