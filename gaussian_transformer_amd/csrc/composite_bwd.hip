@@ -22,6 +22,7 @@
 namespace gsr {
 
 #define LOG2E 1.4426950408889634f
+#define RED_STRIDE 68
 
 __device__ __forceinline__ int xcd_band_unit(int b, int nblocks_padded) {
     const int chunk = nblocks_padded >> 3;
@@ -110,7 +111,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
     // floats red[value][16*part .. 16*part+15] (4 x ds_read_b128), two DPP steps fold the 4 parts, and
     // lanes 0,4,...,32 hold the nine totals: ONE 9-lane global_atomic_add_f32 per (wave, splat).
     const int rvalue = lane >> 2, rpart = lane & 3;
-    const float4 *red_rd = reinterpret_cast<const float4 *>(red + (rvalue < 9 ? rvalue : 0) * 64 + rpart * 16);
+    // rows of RED_STRIDE = 68 floats: with 64 the nine rows start in the same LDS bank and the 36 reading lanes collide 9-way
+    const float4 *red_rd = reinterpret_cast<const float4 *>(red + (rvalue < 9 ? rvalue : 0) * RED_STRIDE + rpart * 16);
     const bool red_lane = rvalue < 9;
     const int slot = (red_lane && rpart == 0) ? rvalue : -1;
 
@@ -189,9 +191,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
 #endif
 #ifndef GSR_ABL_NOREDUCE
             if (any_ok == 0ull) continue;             // wave-uniform: no pixel of this wave blends the splat
-            red[0 * 64 + lane] = v0; red[1 * 64 + lane] = v1; red[2 * 64 + lane] = v2;
-            red[3 * 64 + lane] = v3; red[4 * 64 + lane] = v4; red[5 * 64 + lane] = v5;
-            red[6 * 64 + lane] = v6; red[7 * 64 + lane] = v7; red[8 * 64 + lane] = v8;
+            red[0 * RED_STRIDE + lane] = v0; red[1 * RED_STRIDE + lane] = v1; red[2 * RED_STRIDE + lane] = v2;
+            red[3 * RED_STRIDE + lane] = v3; red[4 * RED_STRIDE + lane] = v4; red[5 * RED_STRIDE + lane] = v5;
+            red[6 * RED_STRIDE + lane] = v6; red[7 * RED_STRIDE + lane] = v7; red[8 * RED_STRIDE + lane] = v8;
             __builtin_amdgcn_wave_barrier();
             float sel = 0.f;
             if (red_lane) {
