@@ -35,5 +35,15 @@ for st, c in tot.items():
     res[st] = int(rd + wr)
     res[st + ".read"] = int(rd); res[st + ".write"] = int(wr)
 res["per_render_total"] = int(sum(v for k, v in res.items() if "." in k and k.count(".") == 1))
+# VALU pipe utilisation of the two compositing kernels from the SQ / GRBM passes (scripts/pmc_summary.py's JSON):
+#   busy = SQ_ACTIVE_INST_VALU [quad-cycles] x 4 / (1024 SIMDs x kernel cycles),  kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs
+try:
+    summ = json.load(open(os.path.join(d, f"{tag}_summary.json")))
+    for k, v in summ.items():
+        for pat, st in (("composite_bwd_kernel", "bwd.composite"), ("composite_fwd_kernel", "fwd.composite")):
+            if pat in k and v.get("GRBM_GUI_ACTIVE") and v.get("SQ_ACTIVE_INST_VALU"):
+                res[st + ".valu_busy"] = round(v["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * v["GRBM_GUI_ACTIVE"] / 8.0), 4)
+except Exception:
+    pass
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
