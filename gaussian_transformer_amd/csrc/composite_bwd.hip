@@ -6,16 +6,17 @@
 // work that does not depend on the pixel (LDS record read, loop control, the cross-lane gradient
 // reduction, the atomic) is paid once per NPX*64 pixels.  Waves never synchronise with each other
 // (no workgroup barrier): each stages the tile's splat list 64 records at a time into a
-// wave-private LDS slice, one record gathered per lane.  While staging, the lane also decides,
-// per 8x8 block, whether the splat can reach alpha >= 1/255 anywhere in the block (exact min of
-// the quadratic form over the block rectangle against the culling threshold of gsr_device.h); the
+// wave-private LDS slice, one record gathered per lane.  While staging, the lane also reads, per
+// 8x8 block, whether the splat can reach alpha >= 1/255 anywhere in the block -- one byte per block
+// and list entry that the forward pass wrote when it staged the same entry (exact min of the
+// quadratic form over the block rectangle against the culling threshold of gsr_device.h); the
 // wave then walks only the set bits of the 64-bit ballot, so dead splats cost two scalar
 // instructions, and dead blocks of a live splat are skipped by a scalar branch.
-// All lanes visit the same splat at the same step, so the nine partial gradients are summed in
-// registers: v_permlane32_swap / v_permlane16_swap fold value PAIRS across the wave halves and
-// rows in two instructions per fold (keep-one/send-one, no select), four DPP steps finish the
-// 16-lane rows, and the nine totals leave as ONE global_atomic_add_f32 instruction (9 lanes) into
-// the splat's 64-byte accumulator row: one memory-side request per (wave, splat).
+// All lanes visit the same splat at the same step.  The nine partial gradients are reduced through
+// LDS (the VALU is the bottleneck of this kernel, the LDS pipe is idle): every lane stores its nine
+// values as rows of 68 floats (bank-conflict-free for the readers), 36 lanes each add 16 of them with
+// four ds_read_b128, two DPP steps finish, and the nine totals leave as ONE global_atomic_add_f32
+// instruction (9 lanes) into the splat's 64-byte accumulator row: one memory-side request per (wave, splat).
 #include "gsr_device.h"
 #include "gsr_internal.h"
 
