@@ -9,7 +9,8 @@
 // block whether its splat can reach alpha >= 1/255 anywhere in the block (exact minimum of the
 // quadratic form over the block rectangle, gsr_device.h); the wave then walks only the set bits of
 // the ballot -- dead splats cost two scalar instructions -- and skips dead blocks of a live splat
-// with a scalar branch.  The conic is pre-scaled by -0.5*log2(e) / -log2(e) at staging time so the
+// with a scalar branch.  The per-block bits are also stored (one byte per block and list entry) for the
+// reverse pass, which stages the same entries against the same blocks.  The conic is pre-scaled by -0.5*log2(e) / -log2(e) at staging time so the
 // per-pixel exponent feeds v_exp_f32 directly.
 // blockIdx is remapped so that each XCD (blocks b, b+8, ... share one) walks a contiguous band
 // of tiles: neighbouring tiles share splats, which keeps the record gathers in that XCD's L2.
