@@ -54,6 +54,7 @@ SIGNATURES = {
     "gsr_debug_read_geom": (_i32, [_p, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "gsr_debug_read_binning": (_i32, [_p, C.c_int64, _i32, _i32, _p, _p, _p, _p, _p]),
     "gsr_debug_read_image_state": (_i32, [_p, _i32, _i32, _p, _p, _p]),
+    "gsr_debug_read_lane_counters": (_i32, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gsr_l1_ssim_workspace": (_i32, [_i32, _i32, _i32, C.POINTER(_sz)]),
     "gsr_l1_ssim_forward": (_i32, [_p, _i32, _i32, _i32, _p, _p, _f, _p, _p, _sz]),
     "gsr_l1_ssim_backward": (_i32, [_p, _i32, _i32, _i32, _p, _p, _f, _p, _p, _sz, _p]),
@@ -118,3 +119,24 @@ def get_option(name: str) -> int:
     v = C.c_int32(0)
     check(load().gsr_get_option(name.encode(), C.byref(v)), f"gsr_get_option({name})")
     return int(v.value)
+
+
+LANE_COUNTER_NAMES = ("staged", "visits", "block_visits", "lanes_ok", "lanes_past_last", "lanes_below_alpha",
+                      "reductions", "dead_block_visits", "waves")
+
+
+def read_lane_counters() -> dict:
+    """Lane-slot accounting of the instrumented compositing kernels (set_option("count_lanes", 1) first); reads and
+    resets the current device's counters.  Returns {"fwd": {...}, "bwd": {...}} with a derived "lane_efficiency"
+    = lanes that blended / lane slots issued (64 per 8x8 block visit)."""
+    f = (C.c_uint64 * 16)()
+    b = (C.c_uint64 * 16)()
+    check(load().gsr_debug_read_lane_counters(f, b), "gsr_debug_read_lane_counters")
+    out = {}
+    for tag, arr in (("fwd", f), ("bwd", b)):
+        d = {n: int(arr[i]) for i, n in enumerate(LANE_COUNTER_NAMES)}
+        slots = 64 * d["block_visits"]
+        d["lane_slots"] = slots
+        d["lane_efficiency"] = (d["lanes_ok"] / slots) if slots else 0.0
+        out[tag] = d
+    return out

@@ -54,7 +54,9 @@ __device__ __forceinline__ float fold16(float a, float b) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <int NPX>
+// COUNT: instrumented instantiation (gsr_set_option("count_lanes", 1)): tallies staged records, splat visits, 8x8 block
+// visits (= 64 lane slots each), blending lanes and the reason idle lanes were idle into a.counters (CompositeCounters)
+template <int NPX, bool COUNT>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, int nblocks_padded, int /*exact_cull*/) {
     constexpr int UNITS_PER_TILE = 4 / NPX;          // waves per tile
     extern __shared__ __align__(16) float4 stage_dyn[];     // per wave: 64 records x 3 float4, then 16 x 64 floats of reduction scratch
@@ -69,12 +71,11 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
     const float4 *rec4 = reinterpret_cast<const float4 *>(a.rec);
     const uint2 range = a.ranges[tile];
     const size_t HW = (size_t)a.W * a.H;
-    const float halfW = 0.5f * (float)a.W, halfH = 0.5f * (float)a.H;
     const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 
     // per-pixel state, one pixel per 8x8 block q:  Tr = transmittance behind the splats visited so far,
-    // acc = colour composited behind them (normalised by Tr), d = dL/dpixel, tb = T_final * <bg, d>
-    float fx[NPX], fy[NPX], Tr[NPX], acc0[NPX], acc1[NPX], acc2[NPX];
+    // accd = <colour composited behind them (normalised by Tr), d>, d = dL/dpixel, tb = T_final * <bg, d>
+    float fx[NPX], fy[NPX], Tr[NPX], accd[NPX];
     float d0[NPX], d1[NPX], d2[NPX], tb[NPX];
     int last[NPX];
     int max_last = 0;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
         d1[q] = inside ? a.dL_dpix[HW + pix] : 0.f;
         d2[q] = inside ? a.dL_dpix[2 * HW + pix] : 0.f;
         tb[q] = Tf * (bg0 * d0[q] + bg1 * d1[q] + bg2 * d2[q]);
-        Tr[q] = Tf; acc0[q] = acc1[q] = acc2[q] = 0.f;
+        Tr[q] = Tf; accd[q] = 0.f;
         max_last = max(max_last, last[q]);
     }
     int blk_last[NPX];                                // last contributor over the 64 pixels of block q (wave-uniform)
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
     const bool red_lane = rvalue < 9;
     const int slot = (red_lane && rpart == 0) ? rvalue : -1;
 
+    unsigned long long c_staged = 0, c_visits = 0, c_blocks = 0, c_ok = 0, c_past = 0, c_alpha = 0, c_red = 0, c_dead = 0;
     for (int base = ((max_last - 1) >> 6) << 6; base >= 0; base -= 64) {
         const int cnt = min(64, max_last - base);
         __builtin_amdgcn_wave_barrier();
@@ -132,57 +134,78 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
                 bits |= a.contrib[(size_t)blk * a.contrib_stride + range.x + base + lane] ? (1u << q) : 0u;
             }
             live = bits != 0u;
-            my[lane * 3 + 0] = r0; my[lane * 3 + 1] = r1;
+            const StagedConic sc = stage_conic(r0.z, r0.w, r1.x);       // as the forward pass staged it
+            my[lane * 3 + 0] = make_float4(r0.x, r0.y, sc.a, sc.b);
+            my[lane * 3 + 1] = make_float4(sc.c, r1.y, r1.z, r1.w);
             my[lane * 3 + 2] = make_float4(r2.x, 0.f, __uint_as_float(bits), __uint_as_float(g));
         }
         uint64_t todo = __ballot(live);
+        if (COUNT) { c_staged += cnt; c_visits += __builtin_popcountll(todo); }
         __builtin_amdgcn_wave_barrier();
         while (todo) {
             const int j = 63 - __builtin_clzll(todo);
             todo &= ~(1ull << j);
-            const float4 r0 = my[j * 3 + 0], r1 = my[j * 3 + 1], r2 = my[j * 3 + 2];
+            const float4 *mj = my + (uint32_t)j * 3u;
+            const float4 r0 = mj[0], r1 = mj[1], r2 = mj[2];
             const uint32_t bits = __builtin_amdgcn_readfirstlane(__float_as_uint(r2.z));
-            // Per-lane partial sums over this lane's pixels.  The constant factors of S10 are applied
-            // once per Gaussian in pergauss_bwd.hip:  v3,v4 = sum s*u, s*v  (x -W/2, -H/2 there),
-            // v5..v7 = sum s*dx*dx, s*dx*dy, s*dy*dy (x -1/2 there), with s = o * G * dL/dalpha.
+            // Per-lane partial sums over this lane's pixels: v0..v2 = sum w * dL/dpixel (colour gradient),
+            // v8 = sum s, v3,v4 = sum s*dx, s*dy, v5..v7 = sum s*dx*dx, s*dx*dy, s*dy*dy with s = opacity * G * dL/dalpha
+            // (the pre-cap alpha times dL/dalpha: the 0.99 cap is straight-through, S10).  Everything that is constant
+            // per Gaussian (conic, W/2, H/2, -1/2, 1/opacity for dL/dopacity) is applied once in pergauss_bwd.hip.
             float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
             const int pos = base + j;
             unsigned long long any_ok = 0ull;         // 64-bit lane mask kept in SGPRs
-            // body for one 8x8 block; straight-line so that the blocks of one splat interleave (ILP)
+            const StagedConic kc = {r0.z, r0.w, r1.x};
+            // body for one 8x8 block
             auto block_body = [&](int q) __attribute__((always_inline)) {
                 const float dx = r0.x - fx[q], dy = r0.y - fy[q];
-                const float u = r0.z * dx + r0.w * dy, v = r1.x * dy + r0.w * dx;    // conic * d
-                const float qf = dx * u + dy * v;                                   // = -2 power
-                const float G = __builtin_amdgcn_exp2f(qf * (-0.5f * LOG2E));
-                const float alpha = fminf(GSR_ALPHA_MAX, r1.y * G);
-                const bool ok = (pos < last[q]) && !(qf < 0.f) && !(alpha < GSR_ALPHA_MIN);
-                any_ok |= __ballot(ok);
-                const float a_ok = ok ? alpha : 0.f;
-                const float inv = __builtin_amdgcn_rcpf(1.f - a_ok);
-                const float Tk = Tr[q] * inv;                        // transmittance in front of this splat
-                const float t0 = r1.z - acc0[q], t1 = r1.w - acc1[q], t2 = r2.x - acc2[q];
-                float dL_dalpha = (t0 * d0[q] + t1 * d1[q] + t2 * d2[q]) * Tk - tb[q] * inv;
-                dL_dalpha = ok ? dL_dalpha : 0.f;
-                acc0[q] += a_ok * t0; acc1[q] += a_ok * t1; acc2[q] += a_ok * t2;   // colour behind the next (nearer) splat
-                Tr[q] = Tk;
-                const float w = a_ok * Tk;
-                v0 += w * d0[q]; v1 += w * d1[q]; v2 += w * d2[q];
-                const float g8 = (ok ? G : 0.f) * dL_dalpha;         // exp2 of a skipped lane may be inf
-                const float sg = r1.y * g8;
-                v8 += g8;
-                v3 += sg * u; v4 += sg * v;
-                const float sx = sg * dx, sy = sg * dy;
-                v5 += sx * dx; v6 += sx * dy; v7 += sy * dy;
+                float araw;                                          // same expression, same bits as the forward pass
+                const unsigned long long okm = splat_alpha(splat_power_log2(kc, dx, dy), r1.y, araw) &
+                                               __builtin_amdgcn_ballot_w64(pos < last[q]);
+                any_ok |= okm;
+                if (COUNT) {
+                    const unsigned long long mp = __ballot(!(pos < last[q]));
+                    c_blocks += 1; c_ok += __builtin_popcountll(okm); c_past += __builtin_popcountll(mp);
+                    c_alpha += __builtin_popcountll(~okm & ~mp); c_dead += okm == 0ull;
+                }
+#ifdef GSR_BWD_EXEC_MASK
+                const float alpha = fminf(GSR_ALPHA_MAX, araw);
+                if (__builtin_amdgcn_inverse_ballot_w64(okm)) {      // the other lanes are switched off (EXEC), not multiplied by zero
+                    const float araw_ok = araw;
+#else
+                {   // lanes that do not blend carry alpha = 0 through the same arithmetic: every sum below gets an exact 0
+                    const float araw_ok = __builtin_amdgcn_inverse_ballot_w64(okm) ? araw : 0.f;   // exp2 of a skipped lane may be inf
+                    const float alpha = fminf(GSR_ALPHA_MAX, araw_ok);
+#endif
+                    const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
+                    const float Tk = Tr[q] * inv;                    // transmittance in front of this splat
+                    // <colour - colour behind, dL/dpixel>: the colour behind is only ever needed through this inner
+                    // product, so the recurrence runs on accd = <colour behind, dL/dpixel> (one register, not three)
+                    const float dot = (r1.z * d0[q] + r1.w * d1[q] + r2.x * d2[q]) - accd[q];
+                    const float dL_dalpha = (dot * Tr[q] - tb[q]) * inv;
+                    accd[q] += alpha * dot;                          // behind the next (nearer) splat
+                    Tr[q] = Tk;
+                    const float w = alpha * Tk;
+                    v0 += w * d0[q]; v1 += w * d1[q]; v2 += w * d2[q];
+                    const float sg = araw_ok * dL_dalpha;            // pre-cap alpha: the cap is straight-through (S10)
+                    v8 += sg;
+                    const float sx = sg * dx, sy = sg * dy;
+                    v3 += sx; v4 += sy;
+                    v5 += sx * dx; v6 += sx * dy; v7 += sy * dy;
+                }
             };
 #ifndef GSR_ABL_NOMATH
             uint32_t todo_bits = bits;                // drop blocks whose pixels all stopped before this splat
 #pragma unroll
             for (int q = 0; q < NPX; q++)
                 if (pos >= blk_last[q]) todo_bits &= ~(1u << q);
+#ifdef GSR_BWD_FASTPATH
             if (todo_bits == (1u << NPX) - 1u) {      // scalar branch: every block needed -> one basic block
 #pragma unroll
                 for (int q = 0; q < NPX; q++) block_body(q);
-            } else {
+            } else
+#endif
+            {
 #pragma unroll
                 for (int q = 0; q < NPX; q++)
                     if (todo_bits & (1u << q)) block_body(q);
@@ -192,6 +215,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
 #endif
 #ifndef GSR_ABL_NOREDUCE
             if (any_ok == 0ull) continue;             // wave-uniform: no pixel of this wave blends the splat
+            if (COUNT) c_red += 1;
             red[0 * RED_STRIDE + lane] = v0; red[1 * RED_STRIDE + lane] = v1; red[2 * RED_STRIDE + lane] = v2;
             red[3 * RED_STRIDE + lane] = v3; red[4 * RED_STRIDE + lane] = v4; red[5 * RED_STRIDE + lane] = v5;
             red[6 * RED_STRIDE + lane] = v6; red[7 * RED_STRIDE + lane] = v7; red[8 * RED_STRIDE + lane] = v8;
@@ -220,6 +244,13 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
 #endif
         }
     }
+    if (COUNT && lane == 0 && a.counters) {
+        atomicAdd(&a.counters->staged, c_staged); atomicAdd(&a.counters->visits, c_visits);
+        atomicAdd(&a.counters->block_visits, c_blocks); atomicAdd(&a.counters->lanes_ok, c_ok);
+        atomicAdd(&a.counters->lanes_past_last, c_past); atomicAdd(&a.counters->lanes_below_alpha, c_alpha);
+        atomicAdd(&a.counters->reductions, c_red); atomicAdd(&a.counters->dead_block_visits, c_dead);
+        atomicAdd(&a.counters->waves, 1ull);
+    }
 }
 
 template <int NPX>
@@ -228,8 +259,12 @@ static hipError_t launch_bwd(const CompositeBwdArgs &a, int exact_cull, int wpb,
     const int units = T * (4 / NPX);
     const int blocks = (units + wpb - 1) / wpb;
     const int padded = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL(composite_bwd_kernel<NPX>, dim3(padded), dim3(64 * wpb), (size_t)wpb * (64 * 3 + 16 * 16) * sizeof(float4), s, a,
-                       padded, exact_cull);
+    if (a.counters)
+        hipLaunchKernelGGL((composite_bwd_kernel<NPX, true>), dim3(padded), dim3(64 * wpb), (size_t)wpb * (64 * 3 + 16 * 16) * sizeof(float4), s, a,
+                           padded, exact_cull);
+    else
+        hipLaunchKernelGGL((composite_bwd_kernel<NPX, false>), dim3(padded), dim3(64 * wpb), (size_t)wpb * (64 * 3 + 16 * 16) * sizeof(float4), s, a,
+                           padded, exact_cull);
     return hipGetLastError();
 }
 

@@ -26,7 +26,8 @@ __device__ __forceinline__ int xcd_band_unit_f(int b, int nblocks_padded) {
     return (b & 7) * chunk + (b >> 3);
 }
 
-template <int NPX>
+// COUNT: instrumented instantiation (gsr_set_option("count_lanes", 1)), see CompositeCounters
+template <int NPX, bool COUNT>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int nblocks_padded, int exact_cull) {
     constexpr int UNITS_PER_TILE = 4 / NPX;
     extern __shared__ __align__(16) float4 stage_dyn[];     // [waves per block][64 * 3]
@@ -41,13 +42,16 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
     float4 *my = stage_dyn + wave * (64 * 3);
     const float4 *rec4 = reinterpret_cast<const float4 *>(a.rec);
 
-    // Tr > 0: transmittance of a live pixel;  Tr < 0: the pixel is finished and |Tr| is its final transmittance
-    // (a finished pixel then fails the T test of every later splat by itself: no separate flag to carry)
+    // Per-pixel state: Tr = transmittance so far (it simply stops changing once the pixel is finished), C = colour,
+    // last = 1-based list position of the last blended splat.  Which pixels are finished is kept as one 64-bit lane
+    // mask per block in SGPRs (done[q]): the per-pair decisions are ballots combined with scalar logic, so the
+    // bookkeeping of finished pixels costs no vector instructions.
     float fx[NPX], fy[NPX], Tr[NPX], C0[NPX], C1[NPX], C2[NPX];
     uint32_t last[NPX];
     bool inside[NPX];
     float bxa[NPX], bya[NPX], bxb[NPX], byb[NPX];
-    bool all_done = true;
+    unsigned long long done[NPX];                     // lanes whose pixel is saturated or outside the image
+    uint32_t blk_done = 0;                            // bit q: every pixel of block q is finished (wave-uniform)
 #pragma unroll
     for (int q = 0; q < NPX; q++) {
         const int blk = NPX == 4 ? q : (NPX == 2 ? sub * 2 + q : sub);
@@ -57,16 +61,14 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
         fx[q] = (float)x; fy[q] = (float)y;
         bxa[q] = (float)x0; bya[q] = (float)y0;
         bxb[q] = (float)min(x0 + 7, a.W - 1); byb[q] = (float)min(y0 + 7, a.H - 1);
-        Tr[q] = inside[q] ? 1.f : -1.f; C0[q] = C1[q] = C2[q] = 0.f; last[q] = 0u;
-        all_done = all_done && !inside[q];
+        Tr[q] = 1.f; C0[q] = C1[q] = C2[q] = 0.f; last[q] = 0u;
+        done[q] = __builtin_amdgcn_ballot_w64(!inside[q]);
+        if (done[q] == ~0ull) blk_done |= 1u << q;
     }
+    const uint32_t all_blocks = (1u << NPX) - 1u;
 
-    uint32_t blk_done = 0;                            // bit q: every pixel of block q is saturated (wave-uniform)
-#pragma unroll
-    for (int q = 0; q < NPX; q++)
-        if (__all(Tr[q] < 0.f)) blk_done |= 1u << q;
-    for (int base = 0; base < n; base += 64) {
-        if (__all(all_done)) break;                   // wave-uniform
+    unsigned long long c_staged = 0, c_visits = 0, c_blocks = 0, c_ok = 0, c_past = 0, c_alpha = 0, c_dead = 0;
+    for (int base = 0; base < n && blk_done != all_blocks; base += 64) {
         const int cnt = min(64, n - base);
         __builtin_amdgcn_wave_barrier();
         bool live = false;
@@ -90,47 +92,62 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
                 a.contrib[(size_t)blk * a.contrib_stride + range.x + base + lane] = (uint8_t)((bits >> q) & 1u);
             }
             // (px, py, -0.5*log2e*A, -log2e*B) (-0.5*log2e*C, opacity, r, g) (b, -, block bits, -)
-            r0.z *= -0.5f * LOG2E; r0.w *= -LOG2E; r1.x *= -0.5f * LOG2E;
+            const StagedConic sc = stage_conic(r0.z, r0.w, r1.x);
+            r0.z = sc.a; r0.w = sc.b; r1.x = sc.c;
             my[lane * 3 + 0] = r0; my[lane * 3 + 1] = r1;
             my[lane * 3 + 2] = make_float4(r2.x, 0.f, __uint_as_float(bits), 0.f);
         }
         uint64_t todo = __ballot(live);
+        if (COUNT) c_staged += cnt;
         __builtin_amdgcn_wave_barrier();
         while (todo) {
+            if (COUNT) c_visits += 1;
             const int j = __builtin_ctzll(todo);
             todo &= todo - 1;
-            const float4 r0 = my[j * 3 + 0], r1 = my[j * 3 + 1], r2 = my[j * 3 + 2];
+            const float4 *mj = my + (uint32_t)j * 3u;
+            const float4 r0 = mj[0], r1 = mj[1], r2 = mj[2];
             const uint32_t bits = __builtin_amdgcn_readfirstlane(__float_as_uint(r2.z));
             const uint32_t pos = (uint32_t)(base + j + 1);
-            unsigned long long any_stop = 0ull;       // lane mask in SGPRs
+            const StagedConic kc = {r0.z, r0.w, r1.x};
+            unsigned long long any_stop = 0ull;       // lanes finishing at this splat
 #pragma unroll
             for (int q = 0; q < NPX; q++) {
                 if (!(bits & ~blk_done & (1u << q))) continue;    // scalar branch: unreachable or saturated block
                 const float dx = r0.x - fx[q], dy = r0.y - fy[q];
-                const float power = (r0.z * dx + r0.w * dy) * dx + (r1.x * dy) * dy;   // log2 units
-                const float alpha = fminf(GSR_ALPHA_MAX, r1.y * __builtin_amdgcn_exp2f(power));
-                const bool ok = !(power > 0.f) && !(alpha < GSR_ALPHA_MIN);
+                float araw;                                          // the one evaluation both passes share (gsr_device.h)
+                const unsigned long long okm = splat_alpha(splat_power_log2(kc, dx, dy), r1.y, araw);
+                const float alpha = fminf(GSR_ALPHA_MAX, araw);
                 const float aT = alpha * Tr[q];
-                const float Tn = Tr[q] - aT;                         // = T (1 - alpha); negative for a finished pixel
-                const bool stop = ok && (Tn < GSR_T_MIN);
-                any_stop |= __ballot(stop && Tr[q] > 0.f);           // pixels finishing right now
-                const bool blend = ok && !stop;
-                const float w = blend ? aT : 0.f;
-                C0[q] += r1.z * w; C1[q] += r1.w * w; C2[q] += r2.x * w;
-                Tr[q] = blend ? Tn : (stop ? -fabsf(Tr[q]) : Tr[q]);
-                last[q] = blend ? pos : last[q];
-            }
-            if (any_stop != 0ull) {                   // wave-uniform
-                all_done = true;
-#pragma unroll
-                for (int q = 0; q < NPX; q++) {
-                    const bool dq = Tr[q] < 0.f;
-                    all_done = all_done && dq;
-                    if (__all(dq)) blk_done |= 1u << q;
+                const float Tn = Tr[q] - aT;                         // = T (1 - alpha)
+                // decisions as lane masks: a live pixel that passes the alpha tests either blends the splat or,
+                // if that would take T below 1e-4, stops in front of it (S9)
+                const unsigned long long livem = okm & ~done[q];
+                const unsigned long long stopm = livem & __builtin_amdgcn_ballot_w64(Tn < GSR_T_MIN);
+                const unsigned long long blendm = livem & ~stopm;
+                done[q] |= stopm; any_stop |= stopm;
+                if (COUNT) {
+                    c_blocks += 1; c_ok += __builtin_popcountll(blendm); c_past += __builtin_popcountll(done[q] & ~stopm);
+                    c_alpha += __builtin_popcountll(~blendm & ~(done[q] & ~stopm)); c_dead += blendm == 0ull;
                 }
-                if (__all(all_done)) { todo = 0; }
+                if (__builtin_amdgcn_inverse_ballot_w64(blendm)) {
+                    C0[q] += r1.z * aT; C1[q] += r1.w * aT; C2[q] += r2.x * aT;
+                    Tr[q] = Tn;
+                    last[q] = pos;
+                }
+            }
+            if (any_stop != 0ull) {                   // wave-uniform: some pixel finished, maybe a whole block
+#pragma unroll
+                for (int q = 0; q < NPX; q++)
+                    if (done[q] == ~0ull) blk_done |= 1u << q;
+                if (blk_done == all_blocks) todo = 0;
             }
         }
+    }
+    if (COUNT && lane == 0 && a.counters) {
+        atomicAdd(&a.counters->staged, c_staged); atomicAdd(&a.counters->visits, c_visits);
+        atomicAdd(&a.counters->block_visits, c_blocks); atomicAdd(&a.counters->lanes_ok, c_ok);
+        atomicAdd(&a.counters->lanes_past_last, c_past); atomicAdd(&a.counters->lanes_below_alpha, c_alpha);
+        atomicAdd(&a.counters->dead_block_visits, c_dead); atomicAdd(&a.counters->waves, 1ull);
     }
     const size_t HW = (size_t)a.W * a.H;
     const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
@@ -138,7 +155,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
     for (int q = 0; q < NPX; q++) {
         if (inside[q]) {
             const size_t pix = (size_t)fy[q] * a.W + (size_t)fx[q];
-            const float Tf = fabsf(Tr[q]);
+            const float Tf = Tr[q];
             a.final_T[pix] = Tf;
             a.n_contrib[pix] = last[q];
             a.out_color[pix] = C0[q] + Tf * bg0;
@@ -154,8 +171,12 @@ static hipError_t launch_fwd(const CompositeArgs &a, int exact_cull, int wpb, hi
     const int units = T * (4 / NPX);
     const int blocks = (units + wpb - 1) / wpb;
     const int padded = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL(composite_fwd_kernel<NPX>, dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4), s, a,
-                       padded, exact_cull);
+    if (a.counters)
+        hipLaunchKernelGGL((composite_fwd_kernel<NPX, true>), dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4), s, a,
+                           padded, exact_cull);
+    else
+        hipLaunchKernelGGL((composite_fwd_kernel<NPX, false>), dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4), s, a,
+                           padded, exact_cull);
     return hipGetLastError();
 }
 

@@ -21,6 +21,7 @@
 // Every kernel here is latency-bound (8 MB of keys): the design minimises dependent memory round trips and
 // launches -- preprocess leaves per-workgroup depth extrema, so the whole stage is four launches, and the
 // totals the host needs reach it through pinned memory while the last two kernels run.
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -430,14 +431,17 @@ __global__ __launch_bounds__(DO_SORT_THREADS) void do_local_sort_kernel(int nb, 
 hipError_t launch_depth_order_count(const GeomView &g, int P, int log_map, uint32_t *host_out, uint32_t seq, hipStream_t s) {
     const DepthOrderPlan pl = depth_order_plan(P, log_map);
     const DepthOrderView &d = g.dord;
-    static bool attr_set = false;   // benign race: the attribute is idempotent
-    if (!attr_set && 2 * pl.nb * sizeof(uint32_t) > 48 * 1024) {
+    static std::atomic<uint64_t> attr_set{0};   // one bit per device (the attribute is per device and idempotent)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t dev_bit = 1ull << (dev & 63);
+    if (!(attr_set.load() & dev_bit) && 2 * pl.nb * sizeof(uint32_t) > 48 * 1024) {
         // only the largest bucket counts need it (2 x 8192 counters = 64 KB next to a few static words); raising the
         // limit when it is not needed costs the kernel ~4 us (measured), so it is set on first use
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(do_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            2 * GSR_DO_MAXB * (int)sizeof(uint32_t));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.fetch_or(dev_bit);
     }
     hipLaunchKernelGGL(do_hist_kernel, dim3(pl.nblk), dim3(DO_CNT_THREADS), 2 * pl.nb * sizeof(uint32_t), s, P, pl.chunk, pl.nb, pl.npre, log_map,
                        reinterpret_cast<const uint32_t *>(g.depth), g.tiles, d.blkmin, d.blkmax, d.blkent, d.hdr, d.gpair);
@@ -448,15 +452,18 @@ hipError_t launch_depth_order_count(const GeomView &g, int P, int log_map, uint3
 hipError_t launch_depth_order_place(const GeomView &g, int P, int log_map, int need_offsets, hipStream_t s) {
     const DepthOrderPlan pl = depth_order_plan(P, log_map);
     const DepthOrderView &d = g.dord;
-    static bool attr_set = false;   // benign race: the attribute is idempotent
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_set{0};   // one bit per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t dev_bit = 1ull << (dev & 63);
+    if (!(attr_set.load() & dev_bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(do_local_sort_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            GSR_DO_CAP * (int)sizeof(uint64_t));
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(do_local_sort_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     GSR_DO_CAP * (int)sizeof(uint64_t));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.fetch_or(dev_bit);
     }
     hipLaunchKernelGGL(do_scatter_kernel, dim3(pl.nblk), dim3(DO_CNT_THREADS), pl.nb * sizeof(uint32_t), s, P, pl.chunk, pl.nb, log_map,
                        reinterpret_cast<const uint32_t *>(g.depth), g.tiles, d.hdr, d.bstart, d.gcur, d.comp);

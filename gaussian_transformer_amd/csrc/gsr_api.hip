@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -27,11 +28,42 @@ static std::atomic<int> g_fwd_npx{2};          // same for the forward compositi
 static std::atomic<int> g_wpb{1};              // waves per workgroup of the compositing kernels (waves are independent)
 static std::atomic<int> g_two_level_sort{1};   // 1: depth order first, then per-tile lists; 0: one global sort on tile<<32|depth
 static std::atomic<int> g_tile_lists{1};       // 1: tile_lists.hip (super-tile entries); 0: key emission + rocPRIM sort + range detection
-static std::atomic<int> g_bucket_fail_p{0x7fffffff};   // smallest P whose buckets overflowed even under the log map: not tried again
-static std::atomic<int> g_depth_log_map{0};    // set once a frame overflowed a depth bucket under the linear map (outliers): log map from then on
 static std::atomic<int> g_depth_buckets{1};    // 0: rocPRIM radix sort + scan; 1: depth_order.hip when P is large enough; 2: always (tests)
+static std::atomic<int> g_count_lanes{0};      // 1: instrumented compositing kernels (lane-slot accounting, slower)
+static std::atomic<int> g_deterministic_bwd{0};   // 1: fixed-order reduction of the reverse pass's partial gradients
 #define GSR_DEPTH_BUCKETS_MIN_P 1024           // measured at P = 10 k: 25 us against 48 us for rocPRIM sort + scan + copy-back
-static float g_stage_ms[GSR_NUM_STAGES] = {0};
+
+// State that adapts to what a device has rendered lives per DEVICE, not per process: a frame with depth outliers on one
+// GPU must not change the path of another GPU driven by the same process (SURVEY 8b "several devices in one process").
+// The knobs above are deliberate process-wide settings (gsr_set_option); everything below is keyed by hipGetDevice().
+#define GSR_MAX_DEVICES 32
+struct DeviceState {
+    std::atomic<int> bucket_fail_p{0x7fffffff};   // smallest P whose buckets overflowed even under the log map: not tried again
+    std::atomic<int> depth_log_map{0};            // set once a frame overflowed a depth bucket under the linear map: log map from then on
+    std::atomic<int> poll_timeouts{0};            // N read-backs whose pinned-word poll timed out (diagnostic)
+    std::mutex mu;                                // guards stage_ms and counters
+    float stage_ms[GSR_NUM_STAGES] = {0};         // last profiled forward / backward on this device
+    CompositeCounters *counters = nullptr;        // [2] device memory: forward, reverse (allocated on first use of count_lanes)
+};
+static DeviceState g_dev[GSR_MAX_DEVICES];
+static DeviceState &dev_state();
+// device buffer of the instrumented compositing kernels (debug facility: the only allocation the library makes besides
+// its pinned read-back words); NULL when counting is off or the allocation failed
+static CompositeCounters *lane_counters(int which) {
+    if (!g_count_lanes.load()) return nullptr;
+    DeviceState &ds = dev_state();
+    std::lock_guard<std::mutex> lk(ds.mu);
+    if (!ds.counters) {
+        if (hipMalloc((void **)&ds.counters, 2 * sizeof(CompositeCounters)) != hipSuccess) { ds.counters = nullptr; return nullptr; }
+        (void)hipMemset(ds.counters, 0, 2 * sizeof(CompositeCounters));
+    }
+    return ds.counters + which;
+}
+static DeviceState &dev_state() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+    return g_dev[d % GSR_MAX_DEVICES];
+}
 static const char *const k_stage_names[GSR_NUM_STAGES] = {
     "fwd.preprocess", "fwd.depth_order+scan", "fwd.readback_N", "fwd.emit_keys", "fwd.sort", "fwd.ranges", "(unused)",
     "fwd.composite", "bwd.zero_acc", "bwd.composite", "bwd.pergauss", "fwd.total", "bwd.total"};
@@ -57,6 +89,7 @@ GeomView carve_geom(void *base, int P, size_t scan_tb, size_t dsort_tb) {
     auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += align_up(bytes); return r; };
     g.rec = (float *)take(n * GSR_REC_FLOATS * sizeof(float));
     g.depth = (float *)take(n * sizeof(float));
+    g.opac = (float *)take(n * sizeof(float));
     g.rect = (uint4 *)take(n * sizeof(uint4));
     g.tiles = (uint32_t *)take(n * sizeof(uint32_t));
     g.offsets = (uint32_t *)take(n * sizeof(uint32_t));
@@ -166,7 +199,9 @@ static ReadbackSlot *acquire_slot() {
         if (!sl.busy.compare_exchange_strong(expect, 1)) continue;
         if (sl.host && sl.device != dev) { sl.busy.store(0); continue; }
         if (!sl.host) {
-            if (hipHostMalloc((void **)&sl.host, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { sl.host = nullptr; sl.busy.store(0); return nullptr; }
+            // coherent + mapped: the kernel's system-scope store must become visible to the polling host while the
+            // stream is still running, whatever HIP_HOST_COHERENT says
+            if (hipHostMalloc((void **)&sl.host, 8 * sizeof(uint32_t), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { sl.host = nullptr; sl.busy.store(0); return nullptr; }
             sl.device = dev;
         }
         return &sl;
@@ -174,8 +209,8 @@ static ReadbackSlot *acquire_slot() {
     return nullptr;
 }
 static void release_slot(ReadbackSlot *sl) { if (sl) sl->busy.store(0); }
-// spin on the sequence word; gives up after ~2 s (the caller then synchronises the stream instead and the slot
-// is retired: its kernel may still write to it)
+// spin on the sequence word; gives up after ~2 s (the caller then synchronises the stream instead, counts the
+// time-out in the device's "poll_timeouts" and reuses the slot: after the synchronisation nothing writes to it)
 static bool wait_seq(const ReadbackSlot *sl, uint32_t seq) {
     timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -194,8 +229,10 @@ struct StageTimer {   // hipEvent pairs on the caller's stream; active only unde
     bool on;
     hipEvent_t ev[GSR_NUM_STAGES + 1];
     int idx[GSR_NUM_STAGES + 1];
+    float ms_out[GSR_NUM_STAGES];
     int n = 0;
-    StageTimer(hipStream_t s_, bool on_) : s(s_), on(on_) {}
+    StageTimer(hipStream_t s_, bool on_) : s(s_), on(on_) { for (float &m : ms_out) m = -1.f; }
+    void zero(int stage) { ms_out[stage] = 0.f; }
     void mark(int stage_about_to_start) {
         if (!on || n > GSR_NUM_STAGES) return;
         if (hipEventCreate(&ev[n]) != hipSuccess) { on = false; return; }
@@ -209,11 +246,16 @@ struct StageTimer {   // hipEvent pairs on the caller's stream; active only unde
         for (int i = 0; i + 1 < n; i++) {
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
-            if (idx[i] >= 0) g_stage_ms[idx[i]] = ms;
+            if (idx[i] >= 0) ms_out[idx[i]] = ms;
         }
         float tot = 0.f;
         (void)hipEventElapsedTime(&tot, ev[0], ev[n - 1]);
-        g_stage_ms[total_slot] = tot;
+        ms_out[total_slot] = tot;
+        {
+            DeviceState &ds = dev_state();
+            std::lock_guard<std::mutex> lk(ds.mu);
+            for (int i = 0; i < GSR_NUM_STAGES; i++) if (ms_out[i] >= 0.f) ds.stage_ms[i] = ms_out[i];
+        }
         for (int i = 0; i < n; i++) (void)hipEventDestroy(ev[i]);
         n = 0;
     }
@@ -232,7 +274,9 @@ int32_t gsr_set_option(const char *name, int32_t value) {
     if (name && !strcmp(name, "exact_tile_cull")) { g_exact_cull.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "two_level_sort")) { g_two_level_sort.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "tile_lists")) { g_tile_lists.store(value ? 1 : 0); return GSR_OK; }
-    if (name && !strcmp(name, "depth_log_map")) { g_depth_log_map.store(value ? 1 : 0); g_bucket_fail_p.store(0x7fffffff); return GSR_OK; }
+    if (name && !strcmp(name, "depth_log_map")) { DeviceState &ds = dev_state(); ds.depth_log_map.store(value ? 1 : 0); ds.bucket_fail_p.store(0x7fffffff); return GSR_OK; }
+    if (name && !strcmp(name, "count_lanes")) { g_count_lanes.store(value ? 1 : 0); return GSR_OK; }
+    if (name && !strcmp(name, "deterministic_bwd")) { g_deterministic_bwd.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "depth_buckets")) {
         if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARGUMENT, "depth_buckets must be 0, 1 or 2");
         g_depth_buckets.store(value); return GSR_OK;
@@ -257,7 +301,10 @@ int32_t gsr_get_option(const char *name, int32_t *value) {
     if (name && value && !strcmp(name, "fwd_blocks_per_wave")) { *value = g_fwd_npx.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "two_level_sort")) { *value = g_two_level_sort.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "tile_lists")) { *value = g_tile_lists.load(); return GSR_OK; }
-    if (name && value && !strcmp(name, "depth_log_map")) { *value = g_depth_log_map.load(); return GSR_OK; }
+    if (name && value && !strcmp(name, "depth_log_map")) { *value = dev_state().depth_log_map.load(); return GSR_OK; }
+    if (name && value && !strcmp(name, "count_lanes")) { *value = g_count_lanes.load(); return GSR_OK; }
+    if (name && value && !strcmp(name, "deterministic_bwd")) { *value = g_deterministic_bwd.load(); return GSR_OK; }
+    if (name && value && !strcmp(name, "poll_timeouts")) { *value = dev_state().poll_timeouts.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "depth_buckets")) { *value = g_depth_buckets.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "composite_waves_per_block")) { *value = g_wpb.load(); return GSR_OK; }
     return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_get_option: unknown option '%s'", name ? name : "(null)");
@@ -265,9 +312,11 @@ int32_t gsr_get_option(const char *name, int32_t *value) {
 
 int32_t gsr_set_profiling(int32_t enable) { g_profiling.store(enable ? 1 : 0); return GSR_OK; }
 int32_t gsr_get_stage_times(const char **names, float *ms) {
+    DeviceState &ds = dev_state();
+    std::lock_guard<std::mutex> lk(ds.mu);
     for (int i = 0; i < GSR_NUM_STAGES; i++) {
         if (names) names[i] = k_stage_names[i];
-        if (ms) ms[i] = g_stage_ms[i];
+        if (ms) ms[i] = ds.stage_ms[i];
     }
     return GSR_OK;
 }
@@ -351,13 +400,14 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     const bool want_tile_lists = g_tile_lists.load() != 0 && two_level && tile_list_plan(P, 0, W, H).S <= GSR_TL_MAX_S;
     int P_list = P;                                   // entries of the depth-ordered list (perm / offsets)
     const int dbopt = g_depth_buckets.load();
-    bool bucketed = dbopt == 2 || (dbopt == 1 && P >= GSR_DEPTH_BUCKETS_MIN_P && P < g_bucket_fail_p.load());
+    DeviceState &ds = dev_state();
+    bool bucketed = dbopt == 2 || (dbopt == 1 && P >= GSR_DEPTH_BUCKETS_MIN_P && P < ds.bucket_fail_p.load());
     if (bucketed) {
         uint32_t h[4] = {1u, 0u, 0u, 0u};
         ReadbackSlot *sl = debug ? nullptr : acquire_slot();
         const uint32_t seq = sl ? (g_seq.fetch_add(1) | 0x80000000u) : 0u;
         if (sl) sl->host[4] = 0u;
-        const int log_map = g_depth_log_map.load();
+        const int log_map = ds.depth_log_map.load();
         hipError_t e = launch_depth_order_count(g, P, log_map, sl ? sl->host : nullptr, seq, s);
         if (e == hipSuccess) e = launch_depth_order_place(g, P, log_map, want_tile_lists ? 0 : 1, s);   // runs while the host waits for the totals
         if (e == hipSuccess && want_tile_lists) e = launch_tile_lists_count(g, P, g.dord.hdr, W, H, s);
@@ -367,18 +417,21 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
         if (sl && wait_seq(sl, seq)) {
             h[0] = sl->host[0]; h[1] = sl->host[1]; h[2] = sl->host[2]; h[3] = sl->host[3];
             release_slot(sl);
-        } else {                                      // no slot, debug mode, or the poll timed out (slot stays retired)
-            HIP_TRY(hipMemcpyAsync(h, g.dord.hdr + DO_OVERFLOW, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read N");
-            HIP_TRY(hipStreamSynchronize(s), "read N sync");
+        } else {                                      // no slot, debug mode, or the poll timed out
+            hipError_t ce = hipMemcpyAsync(h, g.dord.hdr + DO_OVERFLOW, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+            if (ce == hipSuccess) ce = hipStreamSynchronize(s);
+            // the stream has drained: the kernel that writes the slot has finished, so the slot is free again
+            if (sl) { ds.poll_timeouts.fetch_add(1); release_slot(sl); }
+            if (ce != hipSuccess) return fail(GSR_ERR_HIP, "read N: %s (%d)", hipGetErrorString(ce), (int)ce);
         }
         e32 = h[3];
         if (h[0]) {               // a bucket exceeds the LDS capacity: general sort below, log map next time
             bucketed = false;
             if (log_map) {        // already the robust map: stop paying for the attempt at this size
-                int cur = g_bucket_fail_p.load();
-                while (P < cur && !g_bucket_fail_p.compare_exchange_weak(cur, P)) {}
+                int cur = ds.bucket_fail_p.load();
+                while (P < cur && !ds.bucket_fail_p.compare_exchange_weak(cur, P)) {}
             }
-            g_depth_log_map.store(1);
+            ds.depth_log_map.store(1);
         }
         else { P_list = (int)h[1]; n32 = h[2]; }
     }
@@ -411,7 +464,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
         if (!bin_ptr) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL for %zu bytes (N=%lld)", total, (long long)N);
         b = carve_binning(bin_ptr, N, 0);
         tv = carve_tile_lists(bin_ptr + pl_bytes, tlp, E);
-        if (tm.on) { g_stage_ms[3] = 0.f; g_stage_ms[5] = 0.f; }      // no key emission / range detection on this path
+        tm.zero(3); tm.zero(5);                         // no key emission / range detection on this path
         tm.mark(4);
         HIP_TRY(launch_tile_lists(g, tv, im, b.point_list, P, P_list, E, W, H, pa.exact_cull, s), "tile lists");
         if (debug) HIP_TRY(hipStreamSynchronize(s), "tile lists");
@@ -440,6 +493,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     ca.W = W; ca.H = H; ca.gridx = gridx; ca.gridy = gridy; ca.ranges = im.ranges; ca.point_list = b.point_list;
     ca.contrib = b.contrib; ca.contrib_stride = (size_t)(N > 0 ? N : 1);
     ca.rec = g.rec; ca.bg = bg; ca.final_T = im.final_T; ca.n_contrib = im.n_contrib; ca.out_color = out_color;
+    ca.counters = lane_counters(0);
     HIP_TRY(launch_composite_fwd(ca, g_fwd_npx.load(), pa.exact_cull, g_wpb.load(), s), "composite launch");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "composite");
     tm.mark(-1);
@@ -496,6 +550,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
         ca.contrib = b.contrib; ca.contrib_stride = (size_t)R;
         ca.rec = g.rec; ca.bg = bg; ca.final_T = im.final_T; ca.n_contrib = im.n_contrib; ca.dL_dpix = dL_dpix;
         ca.acc = (float *)bwd_ws;
+        ca.counters = lane_counters(1);
         HIP_TRY(launch_composite_bwd(ca, g_bwd_npx.load(), g_exact_cull.load(), g_wpb.load(), s), "composite backward launch");
         if (debug) HIP_TRY(hipStreamSynchronize(s), "composite backward");
     }
@@ -505,7 +560,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     pa.P = P; pa.D = D; pa.M = M; pa.W = W; pa.H = H; pa.means3D = means3D; pa.shs = shs; pa.colors_precomp = colors_precomp;
     pa.scales = scales; pa.rotations = rotations; pa.cov3D_precomp = cov3D_precomp; pa.viewmatrix = viewmatrix;
     pa.projmatrix = projmatrix; pa.campos = campos; pa.scale_modifier = scale_modifier; pa.tanfovx = tanfovx;
-    pa.tanfovy = tanfovy; pa.radii = radii; pa.clamped = g.clamped; pa.acc = (const float *)bwd_ws;
+    pa.tanfovy = tanfovy; pa.radii = radii; pa.clamped = g.clamped; pa.opac = g.opac; pa.acc = (const float *)bwd_ws;
     pa.dL_dmeans2D = dL_dmeans2D; pa.dL_dopacity = dL_dopacity; pa.dL_dcolors = dL_dcolors; pa.dL_dmeans3D = dL_dmeans3D;
     pa.dL_dcov3D = dL_dcov3D; pa.dL_dsh = dL_dsh; pa.dL_dscales = dL_dscales; pa.dL_drots = dL_drots;
     HIP_TRY(launch_pergauss_bwd(pa, s), "per-Gaussian backward launch");
@@ -648,6 +703,22 @@ int32_t gsr_debug_read_binning(gsr_stream_t stream, int64_t N, int32_t W, int32_
             free(tmp);
         }
     }
+    return GSR_OK;
+}
+
+int32_t gsr_debug_read_lane_counters(uint64_t *fwd, uint64_t *bwd) {
+    DeviceState &ds = dev_state();
+    HIP_TRY(hipDeviceSynchronize(), "sync");
+    std::lock_guard<std::mutex> lk(ds.mu);
+    static_assert(sizeof(CompositeCounters) == 16 * sizeof(uint64_t), "counter block is 16 words");
+    if (!ds.counters) {
+        if (fwd) memset(fwd, 0, sizeof(CompositeCounters));
+        if (bwd) memset(bwd, 0, sizeof(CompositeCounters));
+        return GSR_OK;
+    }
+    if (fwd) HIP_TRY(hipMemcpy(fwd, ds.counters, sizeof(CompositeCounters), hipMemcpyDeviceToHost), "copy counters");
+    if (bwd) HIP_TRY(hipMemcpy(bwd, ds.counters + 1, sizeof(CompositeCounters), hipMemcpyDeviceToHost), "copy counters");
+    HIP_TRY(hipMemset(ds.counters, 0, 2 * sizeof(CompositeCounters)), "reset counters");
     return GSR_OK;
 }
 

@@ -278,6 +278,31 @@ __device__ __forceinline__ bool block_reachable(float px, float py, float A, flo
     return q <= tau;
 }
 
+// ---- the per-(pixel, splat) evaluation shared by the forward and the reverse compositing kernels ----------------
+// Both passes must take the SAME discrete decisions for a pair (power > 0 and alpha < 1/255 skips): if the reverse pass
+// skipped a pair the forward pass blended, its transmittance chain T/(1 - alpha) would be off for the rest of the
+// pixel (upstream uses one expression in both kernels).  The expression is therefore spelled out with explicit
+// fma / mul (no contraction freedom left to the compiler) on the conic pre-scaled at staging time by
+// stage_conic(): the exponent comes out in log2 units and feeds v_exp_f32 directly.
+#define GSR_LOG2E 1.4426950408889634f
+struct StagedConic { float a, b, c; };            // (-0.5 log2e A, -log2e B, -0.5 log2e C)
+__device__ __forceinline__ StagedConic stage_conic(float A, float B, float C) {
+    return {A * (-0.5f * GSR_LOG2E), B * (-GSR_LOG2E), C * (-0.5f * GSR_LOG2E)};
+}
+__device__ __forceinline__ float splat_power_log2(const StagedConic &k, float dx, float dy) {
+    const float t = __builtin_fmaf(k.b, dy, k.a * dx);          // a dx + b dy
+    return __builtin_fmaf(k.c * dy, dy, t * dx);                // (a dx + b dy) dx + (c dy) dy
+}
+// araw = opacity * G (alpha before the 0.99 cap) and the skip decision of S9: ok = !(power > 0) && !(alpha < 1/255).
+// alpha = min(0.99, araw) < 1/255 exactly when araw < 1/255, so the decision is taken on araw and the cap is left to
+// the caller (the reverse pass caps after masking).
+// Returned as a 64-bit lane mask (two ballots combined by scalar logic): the kernels keep all their per-pair decisions
+// in SGPR masks and turn them back into a predicate with inverse_ballot only where lanes must be switched off.
+__device__ __forceinline__ unsigned long long splat_alpha(float power_log2, float opacity, float &araw) {
+    araw = opacity * __builtin_amdgcn_exp2f(power_log2);
+    return __builtin_amdgcn_ballot_w64(!(power_log2 > 0.f)) & __builtin_amdgcn_ballot_w64(!(araw < GSR_ALPHA_MIN));
+}
+
 // Load the first 3*K floats of one Gaussian's SH row [M,3] into c[].  16-byte vector loads when
 // the row stride keeps every row 16-byte aligned (M = 4, 8, 12, 16 ...), scalar loads otherwise.
 template <int K>

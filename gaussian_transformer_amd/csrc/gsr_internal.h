@@ -17,7 +17,7 @@ static inline int ceil_log2_u32(uint32_t x) { int b = 0; while ((1u << b) < x &&
 #define GSR_REC_FLOATS 12
 // Gradient accumulator of the reverse compositing pass: one 64-byte row per Gaussian so that the
 // nine atomics of one (tile, Gaussian) pair fall into a single memory-side atomic request.
-//   [0..2] dL/drgb  [3..4] sum s*(conic d) (= dL/dmean2D / -(W/2,H/2))  [5..7] sum s*d d^T (= dL/dconic / -0.5)  [8] dL/dopacity
+//   [0..2] dL/drgb  [3..4] sum s*d  [5..7] sum s*d d^T  [8] sum s,  s = opacity * G * dL/dalpha, d = centre - pixel
 #define GSR_ACC_FLOATS 16
 
 // ---- depth_order.hip: bucketed depth order (replaces the rocPRIM depth sort + ordered scan) ----
@@ -42,6 +42,7 @@ struct DepthOrderView {
 struct GeomView {          // per-Gaussian state, P entries each
     float *rec;            // [P][12]
     float *depth;          // [P]
+    float *opac;           // [P] activated opacity (0 for a culled Gaussian): pergauss_bwd.hip scales the moment sums with it
     uint4 *rect;           // [P] (x0 | x1<<16, y0 | y1<<16, row spans lo, hi): tile rectangle + the tile-row spans of a
                            //     small rectangle (<= 8 rows, <= 15 columns, <= 2 super-tile columns) in one word:
                            //     byte k = (c0 - x0) | (c1 - x0) << 4 of row y0 + k; all ones = not representable
@@ -143,8 +144,18 @@ hipError_t launch_tile_lists(const GeomView &g, const TileListView &v, const Ima
                              int64_t E, int W, int H, int exact_cull, hipStream_t s);
 hipError_t launch_ranges(const BinningView &b, const ImageView &im, int64_t N, int T, int two_level, hipStream_t s);
 
+// lane-slot accounting of one compositing launch (instrumented kernels only; gsr_set_option("count_lanes", 1)).
+// A "block visit" is one evaluation of one splat against one 8x8 pixel block = 64 lane slots; lanes_ok of them
+// blended the splat, lanes_past_last sat on a pixel that was already saturated (forward) / stopped before this
+// splat (reverse), lanes_below_alpha failed the alpha / power tests.
+struct CompositeCounters {
+    unsigned long long staged, visits, block_visits, lanes_ok, lanes_past_last, lanes_below_alpha, reductions,
+        dead_block_visits, waves, pad[7];
+};
+
 struct CompositeArgs {
     int W, H, gridx, gridy;
+    CompositeCounters *counters;   // NULL: plain kernel
     uint8_t *contrib;            // [4][contrib_stride]
     size_t contrib_stride;
     const uint2 *ranges;
@@ -159,6 +170,7 @@ hipError_t launch_composite_fwd(const CompositeArgs &a, int npx, int exact_cull,
 
 struct CompositeBwdArgs {
     int W, H, gridx, gridy;
+    CompositeCounters *counters;   // NULL: plain kernel
     const uint8_t *contrib;      // [4][contrib_stride], from the forward pass
     size_t contrib_stride;
     const uint2 *ranges;
@@ -179,6 +191,7 @@ struct PergaussBwdArgs {
     const float *rec;        // forward record (activated opacity at [5])
     float *dL_dsh_rest;
     const float *means3D, *shs, *colors_precomp, *scales, *rotations, *cov3D_precomp;
+    const float *opac;       // [P] activated opacity as the forward pass used it (GeomView::opac)
     const float *viewmatrix, *projmatrix, *campos;
     float scale_modifier, tanfovx, tanfovy;
     const int *radii;

@@ -30,11 +30,6 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
         const float4 A0 = acc4[0], A1 = acc4[1];
         const float A8 = a.acc[GSR_ACC_FLOATS * si + 8];
         dcol[0] = A0.x; dcol[1] = A0.y; dcol[2] = A0.z;
-        // constant factors of S10 deferred from the compositing kernel (composite_bwd.hip):
-        // mean2D gradient w.r.t. NDC = -(W/2, H/2) * sum s*(conic d);  conic gradient = -1/2 * sum s*d d^T
-        dm2[0] = -0.5f * (float)a.W * A0.w; dm2[1] = -0.5f * (float)a.H * A1.x;
-        const float gA = -0.5f * A1.y, gB = -0.5f * A1.z, gC = -0.5f * A1.w;
-        dop = A8;
 
         const float p[3] = {a.means3D[3 * si], a.means3D[3 * si + 1], a.means3D[3 * si + 2]};
         float pv[3];
@@ -58,6 +53,17 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
         ewa_project(pv, c6, a.viewmatrix, a.tanfovx, a.tanfovy, a.W, a.H, e);
         const float ea = e.a, eb = e.b, ec = e.c;
         const float det = ea * ec - eb * eb;
+        // The compositing kernel (composite_bwd.hip) accumulates moments of s = opacity * G * dL/dalpha over the pixels:
+        // A0.w, A1.x = sum s*d;  A1.yzw = sum s * d d^T;  A8 = sum s.  The factors that are constant per Gaussian
+        // are applied here:
+        //   mean2D gradient w.r.t. NDC = -(W/2, H/2) * conic * sum s*d;   conic gradient = -1/2 * sum s * d d^T;
+        //   dL/dopacity = sum G * dL/dalpha = (sum s) / opacity   (a Gaussian that blends anywhere has opacity >= 1/255)
+        const float opac = a.opac[si];
+        dop = opac > 0.f ? A8 / opac : 0.f;
+        const float det_inv = 1.f / det;                        // the conic as the forward pass formed it (S4)
+        const float cA = ec * det_inv, cB = -eb * det_inv, cC = ea * det_inv;
+        dm2[0] = -0.5f * (float)a.W * (cA * A0.w + cB * A1.x); dm2[1] = -0.5f * (float)a.H * (cB * A0.w + cC * A1.x);
+        const float gA = -0.5f * A1.y, gB = -0.5f * A1.z, gC = -0.5f * A1.w;
         const float d2inv = 1.f / (det * det + GSR_DENOM_EPS);
         if (d2inv != 0.f) {
             const float dL_da = d2inv * (-ec * ec * gA + 2.f * eb * ec * gB + (det - ea * ec) * gC);
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
             drot[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
         }
         if (RAW) {                   // chain through sigmoid / exp / normalize (scene/gaussian_model.py:33-41)
-            const float o = a.rec[GSR_REC_FLOATS * si + 5];
+            const float o = a.opac[si];
             dop *= o * (1.f - o);
             if (!a.cov3D_precomp) {
                 dscale[0] *= s[0]; dscale[1] *= s[1]; dscale[2] *= s[2];

@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
         float4 *rec = reinterpret_cast<float4 *>(a.g.rec) + 3 * si;
         rec[0] = r0; rec[1] = r1; rec[2] = r2;
         a.g.depth[si] = depth_out;
+        a.g.opac[si] = r1.y;
         a.g.rect[si] = rect_out;
         a.g.tiles[si] = tiles_out;
         a.g.clamped[si] = clamp_out;

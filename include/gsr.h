@@ -127,6 +127,15 @@ int32_t gsr_debug_read_binning(gsr_stream_t stream, int64_t N, int32_t W, int32_
 int32_t gsr_debug_read_image_state(gsr_stream_t stream, int32_t W, int32_t H, const void *img_ws,
                                    float *final_T /*[H,W]*/, uint32_t *n_contrib /*[H,W]*/);
 
+/* Lane-slot accounting of the two compositing kernels (pair evaluations against the FP32 vector peak).
+ * After gsr_set_option("count_lanes", 1) every gsr_forward / gsr_backward on the current device runs instrumented
+ * kernels (slower) that accumulate, per direction, 16 words:
+ *   [0] list entries staged  [1] splat visits (a wave evaluates a splat)  [2] 8x8 block visits (64 lane slots each)
+ *   [3] lanes that blended   [4] lanes on a pixel already finished / stopped earlier  [5] lanes failing the alpha tests
+ *   [6] cross-lane reductions + atomics issued (reverse only)  [7] block visits in which no lane blended  [8] waves
+ * This call synchronises the device, copies the words out (either pointer may be NULL) and resets them. */
+int32_t gsr_debug_read_lane_counters(uint64_t *fwd /*[16] host*/, uint64_t *bwd /*[16] host*/);
+
 /* Tuning knobs (process-wide).  Known options:
  *   "exact_tile_cull" (default 1): emit a (Gaussian,tile) pair only if the ellipse
  *        {alpha >= 1/255} can reach a pixel of the tile, instead of every tile of upstream's
@@ -148,11 +157,14 @@ int32_t gsr_debug_read_image_state(gsr_stream_t stream, int32_t W, int32_t H, co
  *   "composite_waves_per_block" (1, 2 or 4; default 1): wave64s per workgroup of the compositing
  *        kernels.  The waves never synchronise, so 1 lets every wave retire (and be replaced) alone.
  *   "fwd_blocks_per_wave", "bwd_blocks_per_wave" (1, 2 or 4; default 2): 8x8 pixel blocks one
- *        wave64 of the forward / reverse compositing kernel owns (4 = a whole 16x16 tile).  Speed only. */
+ *        wave64 of the forward / reverse compositing kernel owns (4 = a whole 16x16 tile).  Speed only.
+ *   "count_lanes" (default 0): instrumented compositing kernels, see gsr_debug_read_lane_counters.
+ * Adaptive state (which depth-bucket map a device uses after it met depth outliers, "depth_log_map") is kept per
+ * DEVICE, not per process; gsr_set_option("depth_log_map", v) sets it for the current device. */
 int32_t gsr_set_option(const char *name, int32_t value);
 int32_t gsr_get_option(const char *name, int32_t *value);
 
-/* Per-stage timing of the last gsr_forward / gsr_backward of this process, milliseconds,
+/* Per-stage timing of the last profiled gsr_forward / gsr_backward on the CURRENT DEVICE, milliseconds,
  * measured with hipEvents on `stream` when profiling was enabled by gsr_set_profiling(1).
  * names: array of GSR_NUM_STAGES const char*; ms: array of GSR_NUM_STAGES floats (host). */
 #define GSR_NUM_STAGES 13

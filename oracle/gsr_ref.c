@@ -102,6 +102,7 @@ typedef struct gsr_ref_state {
     /* image */
     REAL *final_T;
     uint32_t *n_contrib;
+    REAL *margin; /* [H*W] smallest margin of any discrete decision of S9 the pixel took (see below) */
     /* wall-clock seconds of the last forward / backward: preprocess, scan+emit+sort+ranges, composite | composite, per-Gaussian */
     double t_fwd[3], t_bwd[2];
 } gsr_ref_state;
@@ -254,7 +255,7 @@ static void free_state(gsr_ref_state *s) {
     if (!s) return;
     free(s->depth); free(s->xy); free(s->cov3D); free(s->conic_o); free(s->rgb); free(s->radii);
     free(s->tiles_touched); free(s->offsets); free(s->clamped); free(s->keys); free(s->vals);
-    free(s->ranges); free(s->final_T); free(s->n_contrib); free(s);
+    free(s->ranges); free(s->final_T); free(s->n_contrib); free(s->margin); free(s);
 }
 void gsr_ref_free(gsr_ref_state *s) { free_state(s); }
 
@@ -302,6 +303,7 @@ gsr_ref_state *gsr_ref_forward(const gsr_ref_scene *sc, REAL *out_color, int32_t
     st->ranges = (uint32_t *)calloc((size_t)T * 2 + 2, sizeof(uint32_t));
     st->final_T = (REAL *)calloc((size_t)W * H + 1, sizeof(REAL));
     st->n_contrib = (uint32_t *)calloc((size_t)W * H + 1, sizeof(uint32_t));
+    st->margin = (REAL *)calloc((size_t)W * H + 1, sizeof(REAL));
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #else
@@ -410,23 +412,33 @@ gsr_ref_state *gsr_ref_forward(const gsr_ref_scene *sc, REAL *out_color, int32_t
                 if (x >= W || y >= H) continue;
                 REAL Tr = R(1), C[3] = {0, 0, 0};
                 uint32_t last = 0, pos = 0;
+                /* Decision margin (test instrumentation): S9 takes three discrete decisions per pair -- power > 0,
+                 * alpha < 1/255, T(1 - alpha) < 1e-4 -- and an implementation whose exp() differs in the last bit can
+                 * take a borderline one the other way, which moves the pixel by up to ~alpha_min * |c|.  margin = the
+                 * smallest distance of any decision this pixel took from its threshold: relative for the alpha and
+                 * transmittance tests, absolute for the sign of power (whose scale is 1). */
+                REAL mg = R(1);
                 for (uint32_t j = r0; j < r1; j++) {
                     pos++;
                     uint32_t g = st->vals[j];
                     REAL dx = st->xy[2 * (size_t)g] - (REAL)x, dy = st->xy[2 * (size_t)g + 1] - (REAL)y;
                     const REAL *co = st->conic_o + 4 * (size_t)g;
                     REAL power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    REAL araw = co[3] * R_EXP(power);
+                    if (araw >= GSR_ALPHA_MIN * R(0.5)) { REAL m = power < 0 ? -power : power; if (m < mg) mg = m; }
                     if (power > R(0)) continue;
-                    REAL alpha = co[3] * R_EXP(power); if (alpha > GSR_ALPHA_MAX) alpha = GSR_ALPHA_MAX;
+                    REAL alpha = araw; if (alpha > GSR_ALPHA_MAX) alpha = GSR_ALPHA_MAX;
+                    { REAL m = (alpha - GSR_ALPHA_MIN) / GSR_ALPHA_MIN; if (m < 0) m = -m; if (m < mg) mg = m; }
                     if (alpha < GSR_ALPHA_MIN) continue;
                     REAL Tn = Tr * (R(1) - alpha);
+                    { REAL m = (Tn - GSR_T_MIN) / GSR_T_MIN; if (m < 0) m = -m; if (m < mg) mg = m; }
                     if (Tn < GSR_T_MIN) break;
                     const REAL *c = st->rgb + 3 * (size_t)g;
                     for (int ch = 0; ch < 3; ch++) C[ch] += c[ch] * alpha * Tr;
                     Tr = Tn; last = pos;
                 }
                 size_t pix = (size_t)y * W + x;
-                st->final_T[pix] = Tr; st->n_contrib[pix] = last;
+                st->final_T[pix] = Tr; st->n_contrib[pix] = last; st->margin[pix] = mg;
                 for (int ch = 0; ch < 3; ch++) out_color[(size_t)ch * W * H + pix] = C[ch] + Tr * sc->bg[ch];
             }
     }
@@ -651,6 +663,9 @@ void gsr_ref_get_image_state(const gsr_ref_state *s, REAL *final_T, uint32_t *n_
     size_t n = (size_t)s->W * s->H;
     if (final_T) memcpy(final_T, s->final_T, sizeof(REAL) * n);
     if (n_contrib) memcpy(n_contrib, s->n_contrib, sizeof(uint32_t) * n);
+}
+void gsr_ref_get_margin(const gsr_ref_state *s, REAL *margin) {
+    memcpy(margin, s->margin, sizeof(REAL) * (size_t)s->W * s->H);
 }
 void gsr_ref_get_timings(const gsr_ref_state *s, double *fwd3, double *bwd2) {
     for (int i = 0; i < 3; i++) fwd3[i] = s->t_fwd[i];

@@ -216,6 +216,8 @@ def main():
     # the whole SfM cloud of table_ds (17 618 points, a data file of the reference's dataset): a realistic depth /
     # footprint distribution for the GPU parity tests (BASELINE config 2 names this scene)
     shutil.copyfile(os.path.join(model_dir, "points3D.ply"), os.path.join(a.out, "table_points3D.ply"))
+    # the SfM cloud of tiramisu_ds (33 730 points): BASELINE config 4 names this scene
+    shutil.copyfile(os.path.join(a.ref, "tiramisu_ds", "sparse", "0", "points3D.ply"), os.path.join(a.out, "tiramisu_points3D.ply"))
     print("wrote", sorted(os.listdir(a.out)))
 
 

@@ -91,6 +91,7 @@ class RefRasterizer:
         L.gsr_ref_get_geom.argtypes = [C.c_void_p] * 8
         L.gsr_ref_get_binning.argtypes = [C.c_void_p] * 4
         L.gsr_ref_get_image_state.argtypes = [C.c_void_p] * 3
+        L.gsr_ref_get_margin.argtypes = [C.c_void_p] * 2
         L.gsr_ref_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gsr_ref_max_threads.restype = C.c_int32
         L.gsr_ref_get_timings.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -206,6 +207,14 @@ class _State:
         self.owner.lib.gsr_ref_get_timings(self.handle, f, b)
         return {"fwd.preprocess": f[0], "fwd.scan+emit+sort+ranges": f[1], "fwd.composite": f[2],
                 "bwd.composite": b[0], "bwd.pergauss": b[1]}
+
+    def decision_margin(self) -> np.ndarray:
+        """[H,W]: per pixel, the smallest distance of any discrete decision of S9 (power > 0, alpha < 1/255,
+        T(1-alpha) < 1e-4) from its threshold -- relative for alpha and T, absolute for power.  A pixel can only
+        legitimately differ from another correct implementation by more than rounding if this is tiny."""
+        m = np.zeros((self.sc.H, self.sc.W), self.owner.np_real)
+        self.owner.lib.gsr_ref_get_margin(self.handle, m.ctypes.data)
+        return m
 
     def image_state(self) -> dict:
         r = self.owner.np_real
