@@ -34,6 +34,7 @@ SIGNATURES = {
     "gsr_last_error": (C.c_char_p, []),
     "gsr_workspace_sizes": (_i32, [_i32, _i32, _i32, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
     "gsr_binning_bytes": (_i32, [C.c_int64, _i32, _i32, C.POINTER(_sz)]),
+    "gsr_backward_workspace_bytes": (_i32, [_i32, C.c_int64, C.POINTER(_sz)]),
     "gsr_forward": (_i32, [_p, _i32, _i32, _i32, _i32, _i32,          # stream P D M W H
                            _p, _p, _p, _p, _p,                        # bg means3D shs colors opacities
                            _p, _f, _p, _p,                            # scales mod rotations cov3D

@@ -56,7 +56,10 @@ __device__ __forceinline__ float fold16(float a, float b) {
 
 // COUNT: instrumented instantiation (gsr_set_option("count_lanes", 1)): tallies staged records, splat visits, 8x8 block
 // visits (= 64 lane slots each), blending lanes and the reason idle lanes were idle into a.counters (CompositeCounters)
-template <int NPX, bool COUNT>
+// DET: deterministic mode (gsr_set_option("deterministic_bwd", 1)): instead of the float atomics, whose arrival order
+// differs from run to run, every (wave, list entry) stores its nine sums into its own slot of a.det and
+// det_reduce_kernel below adds each Gaussian's slots in a fixed order.  The in-wave reduction is order-fixed already.
+template <int NPX, bool COUNT, bool DET>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, int nblocks_padded, int /*exact_cull*/) {
     constexpr int UNITS_PER_TILE = 4 / NPX;          // waves per tile
     extern __shared__ __align__(16) float4 stage_dyn[];     // per wave: 64 records x 3 float4, then 16 x 64 floats of reduction scratch
@@ -236,8 +239,12 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
 #endif
 #ifndef GSR_ABL_NOATOMIC
             if (touched && slot >= 0) {
-                const uint32_t g = __float_as_uint(r2.w);
-                atomicAdd(a.acc + GSR_ACC_FLOATS * (size_t)g + slot, sel);
+                if (DET) {
+                    a.det[((size_t)(range.x + pos) * UNITS_PER_TILE + sub) * GSR_ACC_FLOATS + slot] = sel;
+                } else {
+                    const uint32_t g = __float_as_uint(r2.w);
+                    atomicAdd(a.acc + GSR_ACC_FLOATS * (size_t)g + slot, sel);
+                }
             }
 #else
             if (touched && slot >= 0 && sel == 123.456f) a.acc[slot] = sel;   // keeps the chain alive, never stores
@@ -253,18 +260,54 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
     }
 }
 
+// Deterministic mode, second half: one lane per Gaussian walks the tiles of its rectangle row-major, finds its entry in
+// each tile's (depth, id)-sorted slice by binary search and adds the slots the waves of that tile left, wave 0 first.
+// The summation order is a function of the scene alone.  Debug facility: no attempt at speed.
+__global__ __launch_bounds__(256) void det_reduce_kernel(CompositeBwdArgs a, int units) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= a.P) return;
+    float sum[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const uint4 rc = a.rect[g];
+    const int x0 = (int)(rc.x & 0xffffu), x1 = (int)(rc.x >> 16), y0 = (int)(rc.y & 0xffffu), y1 = (int)(rc.y >> 16);
+    const uint32_t dg = a.depth_bits[g];
+    if (a.tiles[g] > 0u) {
+        for (int ty = y0; ty < y1; ty++)
+            for (int tx = x0; tx < x1; tx++) {
+                const uint2 r = a.ranges[ty * a.gridx + tx];
+                uint32_t lo = r.x, hi = r.y;
+                while (lo < hi) {                         // first entry with (depth, id) >= (dg, g)
+                    const uint32_t mid = lo + ((hi - lo) >> 1);
+                    const uint32_t id = a.point_list[mid];
+                    const uint32_t dm = a.depth_bits[id];
+                    if (dm < dg || (dm == dg && id < (uint32_t)g)) lo = mid + 1; else hi = mid;
+                }
+                if (lo < r.y && a.point_list[lo] == (uint32_t)g)
+                    for (int u = 0; u < units; u++) {
+                        const float *sl = a.det + ((size_t)lo * units + u) * GSR_ACC_FLOATS;
+#pragma unroll
+                        for (int v = 0; v < 9; v++) sum[v] += sl[v];
+                    }
+            }
+    }
+    float *row = a.acc + GSR_ACC_FLOATS * (size_t)g;
+#pragma unroll
+    for (int v = 0; v < 9; v++) row[v] = sum[v];
+}
+
 template <int NPX>
 static hipError_t launch_bwd(const CompositeBwdArgs &a, int exact_cull, int wpb, hipStream_t s) {
     const int T = a.gridx * a.gridy;
     const int units = T * (4 / NPX);
     const int blocks = (units + wpb - 1) / wpb;
     const int padded = (blocks + 7) / 8 * 8;
-    if (a.counters)
-        hipLaunchKernelGGL((composite_bwd_kernel<NPX, true>), dim3(padded), dim3(64 * wpb), (size_t)wpb * (64 * 3 + 16 * 16) * sizeof(float4), s, a,
-                           padded, exact_cull);
+    const size_t lds = (size_t)wpb * (64 * 3 + 16 * 16) * sizeof(float4);
+    if (a.det) {
+        hipLaunchKernelGGL((composite_bwd_kernel<NPX, false, true>), dim3(padded), dim3(64 * wpb), lds, s, a, padded, exact_cull);
+        hipLaunchKernelGGL(det_reduce_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, 4 / NPX);
+    } else if (a.counters)
+        hipLaunchKernelGGL((composite_bwd_kernel<NPX, true, false>), dim3(padded), dim3(64 * wpb), lds, s, a, padded, exact_cull);
     else
-        hipLaunchKernelGGL((composite_bwd_kernel<NPX, false>), dim3(padded), dim3(64 * wpb), (size_t)wpb * (64 * 3 + 16 * 16) * sizeof(float4), s, a,
-                           padded, exact_cull);
+        hipLaunchKernelGGL((composite_bwd_kernel<NPX, false, false>), dim3(padded), dim3(64 * wpb), lds, s, a, padded, exact_cull);
     return hipGetLastError();
 }
 

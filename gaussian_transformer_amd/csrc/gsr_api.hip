@@ -333,6 +333,14 @@ int32_t gsr_workspace_sizes(int32_t P, int32_t W, int32_t H, size_t *geom_bytes,
     return GSR_OK;
 }
 
+int32_t gsr_backward_workspace_bytes(int32_t P, int64_t R, size_t *bytes) {
+    if (P < 0 || R < 0 || !bytes) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward_workspace_bytes: bad argument");
+    const size_t acc_bytes = align_up((size_t)(P > 0 ? P : 1) * GSR_ACC_FLOATS * sizeof(float));
+    const size_t det_bytes = g_deterministic_bwd.load() ? (size_t)R * (size_t)(4 / g_bwd_npx.load()) * GSR_ACC_FLOATS * sizeof(float) : 0;
+    *bytes = acc_bytes + align_up(det_bytes);
+    return GSR_OK;
+}
+
 int32_t gsr_binning_bytes(int64_t N, int32_t W, int32_t H, size_t *bytes) {
     if (N < 0 || W <= 0 || H <= 0 || !bytes) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_binning_bytes: bad argument");
     size_t stb = 0;
@@ -538,11 +546,17 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
         return fail(GSR_ERR_WORKSPACE, "binning workspace too small for R=%lld", (long long)R);
     const size_t acc_bytes = (size_t)P * GSR_ACC_FLOATS * sizeof(float);
     if (bwd_bytes < acc_bytes) return fail(GSR_ERR_WORKSPACE, "backward workspace %zu < %zu", bwd_bytes, acc_bytes);
+    const bool det = g_deterministic_bwd.load() != 0 && R > 0;
+    const int bwd_npx = g_bwd_npx.load();
+    const size_t det_bytes = det ? (size_t)R * (size_t)(4 / bwd_npx) * GSR_ACC_FLOATS * sizeof(float) : 0;
+    if (det && bwd_bytes < align_up(acc_bytes) + det_bytes)
+        return fail(GSR_ERR_WORKSPACE, "deterministic_bwd: backward workspace %zu < %zu (size it with gsr_backward_workspace_bytes)", bwd_bytes,
+                    align_up(acc_bytes) + det_bytes);
     const int gridx = grid_dim(W), gridy = grid_dim(H);
 
     StageTimer tm(s, g_profiling.load() != 0);
     tm.mark(8);
-    HIP_TRY(hipMemsetAsync(bwd_ws, 0, acc_bytes, s), "zero accumulators");
+    HIP_TRY(hipMemsetAsync(bwd_ws, 0, det ? align_up(acc_bytes) + det_bytes : acc_bytes, s), "zero accumulators");
     tm.mark(9);
     if (R > 0) {
         CompositeBwdArgs ca;
@@ -551,7 +565,9 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
         ca.rec = g.rec; ca.bg = bg; ca.final_T = im.final_T; ca.n_contrib = im.n_contrib; ca.dL_dpix = dL_dpix;
         ca.acc = (float *)bwd_ws;
         ca.counters = lane_counters(1);
-        HIP_TRY(launch_composite_bwd(ca, g_bwd_npx.load(), g_exact_cull.load(), g_wpb.load(), s), "composite backward launch");
+        ca.det = det ? (float *)((char *)bwd_ws + align_up(acc_bytes)) : nullptr;
+        ca.P = P; ca.rect = g.rect; ca.tiles = g.tiles; ca.depth_bits = reinterpret_cast<const uint32_t *>(g.depth);
+        HIP_TRY(launch_composite_bwd(ca, bwd_npx, g_exact_cull.load(), g_wpb.load(), s), "composite backward launch");
         if (debug) HIP_TRY(hipStreamSynchronize(s), "composite backward");
     }
     tm.mark(10);

@@ -181,6 +181,13 @@ struct CompositeBwdArgs {
     const uint32_t *n_contrib;
     const float *dL_dpix;
     float *acc;   // [P][16], zeroed
+    // deterministic mode only (det != NULL): one 16-float slot per (list entry, wave of the tile), zeroed; the geometry
+    // det_reduce_kernel needs to find a Gaussian's entries again
+    float *det;
+    int P;
+    const uint4 *rect;
+    const uint32_t *tiles;
+    const uint32_t *depth_bits;
 };
 hipError_t launch_composite_bwd(const CompositeBwdArgs &a, int npx, int exact_cull, int waves_per_block, hipStream_t s);
 

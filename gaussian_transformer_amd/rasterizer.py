@@ -118,8 +118,9 @@ class HipBackend:
         f32 = dict(dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            _, _, bb = self._sizes(P, W, H)
-            bwd_ws = torch.empty((bb,), dtype=torch.uint8, device=dev)
+            bbs = C.c_size_t()         # depends on the pair count while the deterministic mode is on
+            _lib.check(self.lib.gsr_backward_workspace_bytes(P, int(num_rendered), C.byref(bbs)), "gsr_backward_workspace_bytes")
+            bwd_ws = torch.empty((bbs.value,), dtype=torch.uint8, device=dev)
             has_sr = scales.numel() > 0
             arena = _grad_arena
             if arena is not None and (arena.device != dev or arena.dtype != torch.float32 or not arena.is_contiguous()

@@ -63,6 +63,10 @@ const char *gsr_last_error(void);
  *   bwd_bytes  : scratch used only inside gsr_backward (gradient accumulators) */
 int32_t gsr_workspace_sizes(int32_t P, int32_t W, int32_t H, size_t *geom_bytes, size_t *img_bytes, size_t *bwd_bytes);
 
+/* Size of gsr_backward's scratch workspace for a forward that rendered R pairs: the bwd_bytes of gsr_workspace_sizes,
+ * plus, while the option "deterministic_bwd" is on, one 64-byte slot per (pair, wave of the tile). */
+int32_t gsr_backward_workspace_bytes(int32_t P, int64_t R, size_t *bytes);
+
 /* Size of the binning workspace of the SORT path for N (Gaussian,tile) pairs (informational).  gsr_forward asks the
  * allocator callback for exactly what the path it takes needs: the default tile-list path wants 8 N + 16 E bytes plus
  * small tables, E = (Gaussian, super-tile) entries, which only the device knows. */
@@ -159,6 +163,10 @@ int32_t gsr_debug_read_lane_counters(uint64_t *fwd /*[16] host*/, uint64_t *bwd 
  *   "fwd_blocks_per_wave", "bwd_blocks_per_wave" (1, 2 or 4; default 2): 8x8 pixel blocks one
  *        wave64 of the forward / reverse compositing kernel owns (4 = a whole 16x16 tile).  Speed only.
  *   "count_lanes" (default 0): instrumented compositing kernels, see gsr_debug_read_lane_counters.
+ *   "deterministic_bwd" (default 0): the reverse compositing pass stores the partial gradients of every (wave, pair)
+ *        into a slot of its own and a second kernel adds each Gaussian's slots in a fixed order, instead of float
+ *        atomics whose order differs from run to run: bitwise reproducible gradients (race detection).
+ *        Needs the larger scratch of gsr_backward_workspace_bytes; slower (debug mode).
  * Adaptive state (which depth-bucket map a device uses after it met depth outliers, "depth_log_map") is kept per
  * DEVICE, not per process; gsr_set_option("depth_log_map", v) sets it for the current device. */
 int32_t gsr_set_option(const char *name, int32_t value);

@@ -287,6 +287,7 @@ static double now_s(void) {
 static int ceil_log2_u32(uint32_t x) { int b = 0; while ((1u << b) < x && b < 31) b++; return b; }
 
 /* ------------------------------------------------------------------------------------------ */
+static inline int band_skips(int ty);
 /* forward: S1..S9.  out_color [3,H,W], radii [P] (both caller-owned).  Returns state or NULL. */
 gsr_ref_state *gsr_ref_forward(const gsr_ref_scene *sc, REAL *out_color, int32_t *radii, int32_t nthreads) {
     const int P = sc->P, W = sc->W, H = sc->H;
@@ -405,6 +406,7 @@ gsr_ref_state *gsr_ref_forward(const gsr_ref_scene *sc, REAL *out_color, int32_t
 #pragma omp parallel for schedule(dynamic, 1)
     for (int t = 0; t < T; t++) {
         int tx = t % gridx, ty = t / gridx;
+        if (band_skips(ty)) continue;
         uint32_t r0 = st->ranges[2 * (size_t)t], r1 = st->ranges[2 * (size_t)t + 1];
         for (int ly = 0; ly < GSR_TILE; ly++)
             for (int lx = 0; lx < GSR_TILE; lx++) {
@@ -446,6 +448,13 @@ gsr_ref_state *gsr_ref_forward(const gsr_ref_scene *sc, REAL *out_color, int32_t
     return st;
 }
 
+/* Timing aid for bench.py's single-thread baseline leg: restrict the two compositing stages (S9, S10) to the tile rows
+ * [ty0, ty1) so that a bounded sample of a large render can be timed; ty1 <= ty0 (the default) = the whole image.  Pixels
+ * outside the band keep colour 0 / n_contrib 0 and contribute no gradient: NOT a valid render, timing only. */
+static int g_band_ty0 = 0, g_band_ty1 = 0;
+void gsr_ref_set_tile_row_band(int32_t ty0, int32_t ty1) { g_band_ty0 = ty0; g_band_ty1 = ty1; }
+static inline int band_skips(int ty) { return g_band_ty1 > g_band_ty0 && (ty < g_band_ty0 || ty >= g_band_ty1); }
+
 static inline void atomic_add_real(REAL *p, REAL v) {
 #pragma omp atomic
     *p += v;
@@ -478,6 +487,7 @@ int gsr_ref_backward(const gsr_ref_scene *sc, gsr_ref_state *st, const REAL *dL_
 #pragma omp parallel for schedule(dynamic, 1)
     for (int t = 0; t < T; t++) {
         int tx = t % gridx, ty = t / gridx;
+        if (band_skips(ty)) continue;
         uint32_t r0 = st->ranges[2 * (size_t)t];
         for (int ly = 0; ly < GSR_TILE; ly++)
             for (int lx = 0; lx < GSR_TILE; lx++) {

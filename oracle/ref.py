@@ -92,6 +92,7 @@ class RefRasterizer:
         L.gsr_ref_get_binning.argtypes = [C.c_void_p] * 4
         L.gsr_ref_get_image_state.argtypes = [C.c_void_p] * 3
         L.gsr_ref_get_margin.argtypes = [C.c_void_p] * 2
+        L.gsr_ref_set_tile_row_band.argtypes = [C.c_int32, C.c_int32]
         L.gsr_ref_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gsr_ref_max_threads.restype = C.c_int32
         L.gsr_ref_get_timings.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -168,6 +169,10 @@ class RefRasterizer:
         out = np.zeros((m.shape[0],), dtype=np.uint8)
         self.lib.gsr_ref_mark_visible(m.shape[0], m.ctypes.data, v.ctypes.data, out.ctypes.data)
         return out.astype(bool)
+
+    def set_tile_row_band(self, ty0: int = 0, ty1: int = 0) -> None:
+        """Timing aid (bench.py single-thread leg): composite only tile rows [ty0, ty1); (0, 0) = whole image."""
+        self.lib.gsr_ref_set_tile_row_band(int(ty0), int(ty1))
 
     def max_threads(self) -> int:
         return int(self.lib.gsr_ref_max_threads())

@@ -34,7 +34,7 @@ for st, c in tot.items():
     wr = c.get("WRITE_SIZE", 0.0) * 1024.0
     res[st] = int(rd + wr)
     res[st + ".read"] = int(rd); res[st + ".write"] = int(wr)
-res["per_render_total"] = int(sum(v for k, v in res.items() if "." in k and k.count(".") == 1))
+res["per_render_total"] = int(sum(v for k, v in res.items() if isinstance(v, int) and "." in k and k.count(".") == 1))
 # VALU pipe utilisation of the two compositing kernels from the SQ / GRBM passes (scripts/pmc_summary.py's JSON):
 #   busy = SQ_ACTIVE_INST_VALU [quad-cycles] x 4 / (1024 SIMDs x kernel cycles),  kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs
 try:
@@ -45,5 +45,15 @@ try:
                 res[st + ".valu_busy"] = round(v["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * v["GRBM_GUI_ACTIVE"] / 8.0), 4)
 except Exception:
     pass
+# tie the figures to the kernels they were measured on: bench.py quotes them only while the native sources are unchanged
+import hashlib, time
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_h = hashlib.sha256()
+_csrc = os.path.join(_root, "gaussian_transformer_amd", "csrc")
+for _n in sorted(os.listdir(_csrc)):
+    if _n.endswith((".hip", ".h")):
+        _h.update(_n.encode()); _h.update(open(os.path.join(_csrc, _n), "rb").read())
+res["kernel_source_sha"] = _h.hexdigest()[:16]
+res["captured"] = time.strftime("%Y-%m-%d %H:%M:%S")
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
