@@ -124,31 +124,37 @@ def main():
         viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=D,
         campos=cam.camera_center, prefiltered=False, debug=False)
     from gaussian_transformer_amd.rasterizer import arena_floats, gradient_arena
-    # N > 1: the backward pass writes the 59 floats/Gaussian of parameter gradients straight into one flat
-    # bucket, which is summed over the ranks with ONE all-reduce (RCCL over xGMI) inside the step.
-    flat = torch.zeros(arena_floats(P, M), dtype=torch.float32, device=dev) if world > 1 else None
-    state = {}
+    # N > 1: the backward pass writes the 59 floats/Gaussian of parameter gradients straight into a flat arena, which
+    # dist.GradientExchange sums over the ranks (RCCL over xGMI).  GSR_EXCHANGE=overlap (default): the exchange of camera k
+    # runs on a side stream while camera k+1 renders into the second arena; the last one is waited for inside the timed
+    # region.  GSR_EXCHANGE=sync: one blocking exchange per step.  GSR_ALLREDUCE=direct: two direct point-to-point phases
+    # instead of RCCL's all-reduce.  GSR_SPARSE=1: exchange only the rows of the union of the ranks' visible Gaussians.
+    ex = None
+    ex_mode = os.environ.get("GSR_EXCHANGE", "overlap")
+    ex_sparse = os.environ.get("GSR_SPARSE", "0") == "1"
+    if world > 1:
+        from gaussian_transformer_amd.dist import GradientExchange
+        ex = GradientExchange(P, M, dev, mode=ex_mode, algo="direct" if os.environ.get("GSR_ALLREDUCE", "rccl") == "direct" else "allreduce",
+                              bucket_bytes=int(os.environ.get("GSR_BUCKET_MB", "64")) << 20)
+        assert ex.arenas[0].numel() == arena_floats(P, M)
+    state = {"exchange": True}
 
     def step():
         means2D = torch.zeros((P, 3), dtype=torch.float32, device=dev, requires_grad=True)
         rast = GaussianRasterizer(raster_settings=rs)
         color, radii = rast(means3D=means3D, means2D=means2D, shs=shs, opacities=opac, scales=scales, rotations=rots)
         if world > 1:
-            with gradient_arena(flat):
+            with gradient_arena(ex.arena()):              # waits (on the stream) for the exchange that last used this arena
                 grads = torch.autograd.grad(color, params, grad_outputs=dL)
-            if os.environ.get("GSR_ALLREDUCE", "rccl") == "direct":      # two direct exchanges instead of RCCL's all-reduce (dist.py)
-                from gaussian_transformer_amd.dist import direct_all_reduce
-                state["scratch"] = state.get("scratch")
-                if state["scratch"] is None:
-                    state["scratch"] = torch.empty(((world - 1) * ((flat.numel() + world - 1) // world),), dtype=flat.dtype, device=dev)
-                direct_all_reduce(flat, scratch=state["scratch"])
-            else:
-                dist.all_reduce(flat)
+            if state["exchange"]:
+                ex.launch(visible=(radii > 0) if ex_sparse else None)
         else:
             grads = torch.autograd.grad(color, params, grad_outputs=dL)
         state["color"], state["grads"] = color, grads
 
     def sync():
+        if ex is not None:
+            ex.finish()                                   # every outstanding exchange is part of the timed work
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -172,6 +178,29 @@ def main():
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
     value = world * args.steps / dt
+
+    # ---- N > 1: what the exchange costs (outside the timed region): the same K steps without it, and K exchanges alone ----
+    exchange = None
+    if ex is not None:
+        bytes_sent = ex.bytes_last
+        state["exchange"] = False
+        sync(); t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync(); compute_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        state["exchange"] = True
+        sync(); t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ex.arena(); ex.launch()
+        sync(); allreduce_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        tt = torch.tensor([compute_ms, allreduce_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        compute_ms, allreduce_ms = (float(x) for x in tt.tolist())
+        exchange = {"mode": ex_mode, "algo": ex.algo, "sparse": ex_sparse, "bucket_MB": ex.bucket_floats * 4 >> 20,
+                    "bytes_sent_per_rank_per_step": int(bytes_sent), "dense_bytes": int(ex.arenas[0].numel() * 4),
+                    "allreduce_ms": round(allreduce_ms, 4), "compute_only_ms_per_step": round(compute_ms, 4),
+                    "exposed_comm_ms": round(max(0.0, ms_per_step - compute_ms), 4),
+                    "note": "allreduce_ms = the exchange alone, back to back; exposed = step time with the exchange - step time without"}
 
     # ---- second pass over the same K steps with per-stage hipEvents on the launch stream ----
     lib = _lib.load()
@@ -331,7 +360,7 @@ def main():
             "value": round(value, 3), "unit": "renders/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "allreduce_bytes_per_step": (flat.numel() * 4 if flat is not None else 0),
+            "allreduce_bytes_per_step": (exchange["bytes_sent_per_rank_per_step"] if exchange else 0), "exchange": exchange,
             "config": {"workload": args.config, "gaussians": P, "width": W, "height": H, "sh_degree": D,
                        "num_rendered_pairs": int(N), "pairs_under_reference_tile_rule": int(N_ref_rule),
                        "cameras_per_step": world,

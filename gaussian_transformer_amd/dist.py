@@ -26,6 +26,9 @@ def direct_all_reduce(flat: torch.Tensor, group=None, scratch: Optional[torch.Te
     """Sum `flat` over the ranks with two direct exchanges instead of a ring: every rank owns one 1/n slice,
     receives that slice from each peer at once (n-1 point-to-point transfers, one per xGMI link), sums, and sends the
     reduced slice back to every peer.  Per link and phase S/n bytes, against 2(n-1)/n S through the slowest link of a ring.
+    The owner adds the n contributions in RANK ORDER (0, 1, ..., n-1, its own in its place), so the result of an element
+    does not depend on which rank owns it, i.e. not on where the element sits in the buffer: a compacted (sparse) exchange
+    gives bitwise the same sums as the dense one, and every rank holds identical bits.
     Point-to-point only (batch_isend_irecv), so it also runs on gloo.  In place; returns `flat`.
     Not the default of bench.py: which of the two is faster on an 8-GPU node has not been measured (one GPU per box here)."""
     world = dist.get_world_size(group)
@@ -42,18 +45,25 @@ def direct_all_reduce(flat: torch.Tensor, group=None, scratch: Optional[torch.Te
     peers = [r for r in range(world) if r != rank]
     to_global = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
     # phase 1: my slice of everyone's buffer comes to me
-    ops, bufs = [], []
+    ops, bufs = [], {}
     for k, r in enumerate(peers):
         buf = scratch[k * per:k * per + mine.numel()]
-        bufs.append(buf)
+        bufs[r] = buf
         if mine.numel():
             ops.append(dist.P2POp(dist.irecv, buf, to_global(r), group))
         if hi(r) > lo(r):
             ops.append(dist.P2POp(dist.isend, flat[lo(r):hi(r)], to_global(r), group))
     for w in (dist.batch_isend_irecv(ops) if ops else []):
         w.wait()
-    for buf in bufs:
-        mine += buf
+    if mine.numel():
+        if rank == 0:
+            for r in peers:
+                mine += bufs[r]
+        else:                                   # canonical order: ((x0 + x1) + x2) + ...
+            tot = bufs[0]
+            for r in range(1, world):
+                tot += (mine if r == rank else bufs[r])
+            mine.copy_(tot)
     # phase 2: the reduced slices go back to everyone
     ops = []
     for r in peers:
@@ -64,6 +74,190 @@ def direct_all_reduce(flat: torch.Tensor, group=None, scratch: Optional[torch.Te
     for w in (dist.batch_isend_irecv(ops) if ops else []):
         w.wait()
     return flat
+
+
+class GradientExchange:
+    """The one exchange step of the data-parallel path: sums the parameter gradients of all ranks' cameras.
+
+    The gradients live in flat float32 "arenas" laid out as rasterizer.gradient_arena fills them
+    ([means3D 3P | shs 3MP | opacity P | scales 3P | rotations 4P]; gsr_backward writes them there directly, no packing
+    copy).  What this class adds to one blocking all-reduce of 236 B/Gaussian (M = 16):
+
+      * overlap   -- launch() enqueues the exchange of the arena just filled on a side stream (RCCL's own stream for
+                     all_reduce(async_op=True), an explicit HIP stream for the direct exchange) and returns; the next
+                     camera's forward + backward run meanwhile into the OTHER arena (double buffering).  wait() / finish()
+                     make the compute stream wait, and must be called before the optimiser reads the gradients.  Within one
+                     iteration that renders B cameras per rank this hides every exchange but the last one without delaying any
+                     update; with B = 1 it is a one-step-delayed update and the caller must want that.
+      * buckets   -- the arena is cut at parameter boundaries into pieces of at most `bucket_bytes`, one collective each,
+                     so the first pieces are on the wire while the later ones are still queued (ring all-reduce is per-link
+                     bound on the xGMI mesh: many medium collectives pipeline better than one 236 MB one).
+      * active SH -- while the active SH degree D is below the stored one (train.py:72-73 raises it every 1000 iterations)
+                     only the first (D+1)^2 coefficient columns of dL/dshs can be non-zero; `sh_active` exchanges just those
+                     (3 instead of 48 floats per Gaussian at degree 0).
+      * sparse    -- `launch(visible=radii > 0)`: a Gaussian outside every camera's frustum has an all-zero gradient row.
+                     The ranks first agree on the union of their visibility masks (one MAX all-reduce of P bytes), compact the
+                     rows of that union, exchange the compacted buffer and scatter the sums back (rows outside the union stay
+                     zero).  With algo="direct" the sums are bitwise those of the dense exchange (see direct_all_reduce).
+    bytes_last: payload bytes this rank handed to the collective(s) in the last launch()."""
+
+    def __init__(self, P: int, M: int, device, has_scale_rot: bool = True, mode: str = "overlap", algo: str = "allreduce",
+                 bucket_bytes: int = 64 << 20, n_buffers: int = 2, group=None):
+        assert mode in ("sync", "overlap") and algo in ("allreduce", "direct")
+        self.P, self.M, self.mode, self.algo, self.group = int(P), int(M), mode, algo, group
+        self.device = torch.device(device)
+        self.sizes = [3 * P, 3 * M * P, P] + ([3 * P, 4 * P] if has_scale_rot else [])
+        self.names = ["means3D", "shs", "opacities"] + (["scales", "rotations"] if has_scale_rot else [])
+        total = sum(self.sizes)
+        self.arenas = [torch.zeros((total,), dtype=torch.float32, device=self.device) for _ in range(max(1, n_buffers if mode == "overlap" else 1))]
+        self.bucket_floats = max(1, int(bucket_bytes) // 4)
+        self.cur = 0
+        self.pending = [None] * len(self.arenas)       # per arena: list of waitables of the exchange in flight
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.scratch = None
+        self.bytes_last = 0
+        self.sh_active = None                            # None = all M coefficient columns
+
+    # ---- buffers ----
+    def arena(self) -> torch.Tensor:
+        """The arena the NEXT backward pass should fill (its previous exchange is waited for first)."""
+        self._wait_index(self.cur)
+        return self.arenas[self.cur]
+
+    def views(self, arena: Optional[torch.Tensor] = None):
+        a = self.arenas[self.cur] if arena is None else arena
+        out, off = {}, 0
+        shapes = {"means3D": (self.P, 3), "shs": (self.P, self.M, 3), "opacities": (self.P, 1), "scales": (self.P, 3), "rotations": (self.P, 4)}
+        for n, k in zip(self.names, self.sizes):
+            out[n] = a[off:off + k].view(shapes[n]); off += k
+        return out
+
+    def _pieces(self, flat: torch.Tensor):
+        """Contiguous pieces of `flat` to exchange: parameter boundaries, then at most bucket_floats each."""
+        segs, off = [], 0
+        for n, k in zip(self.names, self.sizes):
+            segs.append((off, off + k)); off += k
+        out = []
+        for lo, hi in segs:
+            while lo < hi:
+                out.append(flat[lo:min(hi, lo + self.bucket_floats)]); lo += self.bucket_floats
+        return out
+
+    # ---- exchange ----
+    def _reduce(self, t: torch.Tensor, waits: list):
+        self.bytes_last += t.numel() * t.element_size()
+        if self.algo == "direct":
+            per = (t.numel() + self.world - 1) // self.world
+            if self.scratch is None or self.scratch.numel() < (self.world - 1) * per or self.scratch.dtype != t.dtype:
+                self.scratch = torch.empty(((self.world - 1) * per,), dtype=t.dtype, device=t.device)
+            direct_all_reduce(t, self.group, self.scratch)
+        elif self.mode == "overlap":
+            waits.append(dist.all_reduce(t, group=self.group, async_op=True))
+        else:
+            dist.all_reduce(t, group=self.group)
+
+    def launch(self, visible: Optional[torch.Tensor] = None) -> None:
+        """Exchange the current arena (filled by the backward pass that just ran); switches to the next arena."""
+        idx, flat = self.cur, self.arenas[self.cur]
+        self.bytes_last = 0
+        if self.world > 1:
+            waits: list = []
+            side = self.comm_stream is not None and self.mode == "overlap" and self.algo == "direct"
+            if side:
+                self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+            ctx = torch.cuda.stream(self.comm_stream) if side else _NullCtx()
+            with ctx:
+                if visible is not None:
+                    self._launch_sparse(flat, visible, waits)
+                elif self.sh_active is not None and self.sh_active < self.M:
+                    self._launch_active_sh(flat, waits)
+                else:
+                    for piece in self._pieces(flat):
+                        self._reduce(piece, waits)
+                if side:
+                    ev = torch.cuda.Event(); ev.record(self.comm_stream); waits.append(ev)
+            self.pending[idx] = waits
+            if self.mode == "sync":
+                self._wait_index(idx)
+        self.cur = (self.cur + 1) % len(self.arenas)
+
+    def _launch_active_sh(self, flat, waits):
+        v = self.views(flat)
+        K = int(self.sh_active)
+        for n in self.names:
+            if n != "shs":
+                for piece in self._pieces_of(v[n].reshape(-1)):
+                    self._reduce(piece, waits)
+        act = v["shs"][:, :K, :].contiguous()             # [P, K, 3]: the only columns that can be non-zero
+        for piece in self._pieces_of(act.view(-1)):
+            self._reduce(piece, waits)
+        waits.append(_Deferred(lambda: v["shs"][:, :K, :].copy_(act)))
+
+    def _pieces_of(self, t):
+        return [t[lo:lo + self.bucket_floats] for lo in range(0, t.numel(), self.bucket_floats)]
+
+    def _launch_sparse(self, flat, visible, waits):
+        vis = visible.to(torch.uint8).contiguous()
+        self.bytes_last += vis.numel()
+        dist.all_reduce(vis, op=dist.ReduceOp.MAX, group=self.group)      # union of the ranks' visibility masks
+        idx = torch.nonzero(vis, as_tuple=False).squeeze(1)
+        v = self.views(flat)
+        rows = torch.cat([v[n].reshape(self.P, -1) for n in self.names], dim=1)     # [P, 59] view-copy of the arena
+        comp = rows.index_select(0, idx).contiguous()                               # [n_union, 59]
+        for piece in self._pieces_of(comp.view(-1)):
+            self._reduce(piece, waits)
+
+        def scatter():
+            off = 0
+            for n in self.names:
+                w = v[n].reshape(self.P, -1).shape[1]       # rows outside the union are zero on every rank already
+                v[n].reshape(self.P, -1).index_copy_(0, idx, comp[:, off:off + w])
+                off += w
+        waits.append(_Deferred(scatter))
+        self.union_rows = int(idx.numel())
+
+    def _wait_index(self, idx: int) -> None:
+        waits = self.pending[idx]
+        if not waits:
+            return
+        for w in waits:                                   # first the transfers ...
+            if isinstance(w, _Deferred):
+                continue
+            if self.device.type == "cuda" and isinstance(w, torch.cuda.Event):
+                torch.cuda.current_stream(self.device).wait_event(w)
+            else:
+                w.wait()                                  # c10d Work: the current stream waits for the collective
+        for w in waits:                                   # ... then what consumes them (copy-back, scatter), on the compute stream
+            if isinstance(w, _Deferred):
+                w.run()
+        self.pending[idx] = None
+
+    def wait(self, arena_index: Optional[int] = None) -> None:
+        """Make the compute stream wait for the exchange of one arena (default: the one launched last)."""
+        self._wait_index((self.cur - 1) % len(self.arenas) if arena_index is None else arena_index)
+
+    def finish(self) -> None:
+        for i in range(len(self.arenas)):
+            self._wait_index(i)
+
+
+class _Deferred:
+    """Work to run on the compute stream once the collectives queued before it are waited for (copy-back, scatter)."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def run(self):
+        self.fn()
+
+
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
 
 
 class GradientBucket:

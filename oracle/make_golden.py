@@ -26,13 +26,161 @@ import numpy as np
 import torch
 
 
+def scene_io_fixtures(a):
+    """tests/golden/scene_io.npz + scene_io_{cameras,images,points3D}.txt: what the reference's own COLMAP text readers,
+    readColmapCameras, getNerfppNorm, loadCam, camera_to_JSON and GaussianModel.capture()/restore() return on inputs written
+    here.  plyfile is not installed (an empty stand-in module lets scene/dataset_readers.py import; its PLY
+    functions are not called), device="cuda" literals / .cuda() calls are shimmed to stay on the CPU."""
+    import importlib.util, struct, tempfile, types, json
+    from PIL import Image
+    rng = np.random.default_rng(2024)
+    sys.modules.setdefault("plyfile", types.SimpleNamespace(PlyData=None, PlyElement=None))
+    sys.path.insert(1, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))     # simple_knn._C of this repo (import only)
+    _zeros, _cuda, _empty_cache = torch.zeros, torch.Tensor.cuda, torch.cuda.empty_cache
+
+    def zeros_cpu(*args, **kw):
+        kw.pop("device", None)
+        return _zeros(*args, **kw)
+    torch.zeros = zeros_cpu
+    torch.Tensor.cuda = lambda self, *a_, **k_: self
+    torch.cuda.empty_cache = lambda: None
+    out = {}
+    try:
+        spec = importlib.util.spec_from_file_location("ref_colmap_loader", os.path.join(a.ref, "scene", "colmap_loader.py"))
+        cl = importlib.util.module_from_spec(spec); spec.loader.exec_module(cl)
+        # ---- text model written from the shipped table_ds binaries (+ synthetic poses: images.bin is not in the snapshot) ----
+        model_dir = os.path.join(a.ref, "table_ds", "sparse", "0")
+        cam = next(iter(cl.read_intrinsics_binary(os.path.join(model_dir, "cameras.bin")).values()))
+        f = float(cam.params[0])
+        with open(os.path.join(a.out, "scene_io_cameras.txt"), "w") as fh:
+            fh.write("# Camera list with one line of data per camera:\n#   CAMERA_ID, MODEL, WIDTH, HEIGHT, PARAMS[]\n# Number of cameras: 2\n")
+            fh.write(f"1 PINHOLE {cam.width} {cam.height} {f!r} {f * 1.01!r} {float(cam.params[1])!r} {float(cam.params[2])!r}\n")
+            fh.write(f"2 PINHOLE 1600 900 1210.5 1209.25 800.0 450.0\n")
+        raw = open(os.path.join(model_dir, "points3D.bin"), "rb").read()
+        off, K = 8, 16
+        with open(os.path.join(a.out, "scene_io_points3D.txt"), "w") as fh:
+            fh.write("# 3D point list with one line of data per point:\n#   POINT3D_ID, X, Y, Z, R, G, B, ERROR, TRACK[] as (IMAGE_ID, POINT2D_IDX)\n")
+            for _ in range(K):
+                pid, x, y, z, r, g, b, e = struct.unpack_from("<QdddBBBd", raw, off)
+                (track,) = struct.unpack_from("<Q", raw, off + 43)
+                tr = struct.unpack_from("<" + "ii" * track, raw, off + 51)
+                off += 51 + 8 * track
+                fh.write(f"{pid} {x!r} {y!r} {z!r} {r} {g} {b} {e!r} " + " ".join(str(v) for v in tr) + "\n")
+        names = ["IMG_0003.JPG", "IMG_0001.JPG", "IMG_0002.JPG", "IMG_0010.JPG", "IMG_0007.JPG"]
+        with open(os.path.join(a.out, "scene_io_images.txt"), "w") as fh:
+            fh.write("# Image list with two lines of data per image:\n#   IMAGE_ID, QW, QX, QY, QZ, TX, TY, TZ, CAMERA_ID, NAME\n#   POINTS2D[] as (X, Y, POINT3D_ID)\n")
+            for i, nm in enumerate(names):
+                q = rng.normal(size=4); q /= np.linalg.norm(q)
+                t = rng.normal(size=3) * 2.0
+                fh.write(f"{i + 1} " + " ".join(repr(float(v)) for v in (*q, *t)) + f" {1 if i != 3 else 2} {nm}\n")
+                npts = [3, 0, 5, 1, 2][i]
+                fh.write(" ".join(f"{float(rng.uniform(0, 4000))!r} {float(rng.uniform(0, 2200))!r} {int(rng.integers(-1, 500))}" for _ in range(npts)) + "\n")
+        ci = cl.read_intrinsics_text(os.path.join(a.out, "scene_io_cameras.txt"))
+        ce = cl.read_extrinsics_text(os.path.join(a.out, "scene_io_images.txt"))
+        xyz, rgb, err = cl.read_points3D_text(os.path.join(a.out, "scene_io_points3D.txt"))
+        out.update(txt_cam_ids=np.array(sorted(ci)), txt_cam_wh=np.array([[ci[k].width, ci[k].height] for k in sorted(ci)]),
+                   txt_cam_params=np.array([ci[k].params for k in sorted(ci)]), txt_img_ids=np.array(sorted(ce)),
+                   txt_img_q=np.array([ce[k].qvec for k in sorted(ce)]), txt_img_t=np.array([ce[k].tvec for k in sorted(ce)]),
+                   txt_img_cam=np.array([ce[k].camera_id for k in sorted(ce)]), txt_img_names=np.array([ce[k].name for k in sorted(ce)]),
+                   txt_img_npts=np.array([len(ce[k].point3D_ids) for k in sorted(ce)]),
+                   txt_img_xys2=ce[3].xys, txt_img_p3d2=ce[3].point3D_ids, txt_xyz=xyz, txt_rgb=rgb, txt_err=err)
+        # ---- camera records, NeRF++ normalisation, training cameras, cameras.json ----
+        from scene import dataset_readers as dr
+        from utils import camera_utils as cu
+        with tempfile.TemporaryDirectory() as td:
+            for nm in names:                                  # the images only have to exist and have a size
+                w, h = (cam.width, cam.height) if nm != "IMG_0010.JPG" else (1600, 900)
+                Image.new("RGB", (w // 8, h // 8), (40, 90, 160)).resize((w, h)).save(os.path.join(td, nm), quality=30)
+            infos = dr.readColmapCameras(cam_extrinsics=ce, cam_intrinsics=ci, images_folder=td)
+            infos = sorted(infos.copy(), key=lambda x: x.image_name)
+            norm = dr.getNerfppNorm(infos)
+            out.update(info_names=np.array([c.image_name for c in infos]), info_uid=np.array([c.uid for c in infos]),
+                       info_R=np.array([c.R for c in infos]), info_T=np.array([c.T for c in infos]),
+                       info_fovx=np.array([c.FovX for c in infos]), info_fovy=np.array([c.FovY for c in infos]),
+                       info_wh=np.array([[c.width, c.height] for c in infos]), norm_translate=norm["translate"], norm_radius=norm["radius"])
+            res_cases = [(1, 1.0), (2, 1.0), (4, 1.0), (8, 1.0), (-1, 1.0), (-1, 2.0), (800, 1.0), (1000, 1.5), (3, 1.0), (2, 2.0)]
+            wh = []
+            for res, rs in res_cases:
+                args_ = types.SimpleNamespace(resolution=res, data_device="cpu")
+                row = []
+                for j in (0, 4):                              # a 4032 x 2268 image and the 1600 x 900 one (IMG_0010)
+                    c = cu.loadCam(args_, j, infos[j], rs)
+                    row.append([c.image_width, c.image_height])
+                wh.append(row)
+            out.update(res_cases=np.array(res_cases), res_wh=np.array(wh))
+            args_ = types.SimpleNamespace(resolution=-1, data_device="cpu")
+            cams = cu.cameraList_from_camInfos(infos, 1.0, args_)
+            out.update(cam_wvt=np.array([c.world_view_transform.numpy() for c in cams]), cam_full=np.array([c.full_proj_transform.numpy() for c in cams]),
+                       cam_center=np.array([c.camera_center.numpy() for c in cams]), cam_wh=np.array([[c.image_width, c.image_height] for c in cams]))
+            js = [cu.camera_to_JSON(i, c_) for i, c_ in enumerate(infos)]        # Scene.__init__ passes the CameraInfo records
+            out["cameras_json"] = np.array(json.dumps(js))
+        # ---- checkpoint tuple: GaussianModel.capture() / restore() ----
+        from scene.gaussian_model import GaussianModel
+        from arguments import OptimizationParams
+        import argparse as _ap
+        opt = OptimizationParams(_ap.ArgumentParser())
+        g = torch.Generator().manual_seed(4321)
+        P, deg = 50, 2
+        M = (deg + 1) ** 2
+        init = dict(xyz=torch.randn(P, 3, generator=g), f_dc=torch.randn(P, 1, 3, generator=g) * 0.5,
+                    f_rest=torch.randn(P, M - 1, 3, generator=g) * 0.1, opacity=torch.randn(P, 1, generator=g) * 2.0,
+                    scaling=torch.randn(P, 3, generator=g) * 0.8 - 2.5, rotation=torch.randn(P, 4, generator=g))
+        gm = GaussianModel(deg)
+        gm.active_sh_degree = 1
+        gm._xyz, gm._features_dc, gm._features_rest = (torch.nn.Parameter(init[k].clone()) for k in ("xyz", "f_dc", "f_rest"))
+        gm._opacity, gm._scaling, gm._rotation = (torch.nn.Parameter(init[k].clone()) for k in ("opacity", "scaling", "rotation"))
+        gm.max_radii2D = torch.rand(P, generator=g) * 30
+        gm.spatial_lr_scale = 3.5
+        gm.training_setup(opt)
+        names_ = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+        grads = {k: torch.randn(init[k].shape, generator=g) * 0.01 for k in names_}
+        gm.update_learning_rate(7)
+        for grp in gm.optimizer.param_groups:
+            grp["params"][0].grad = grads[grp["name"]].clone()
+        gm.optimizer.step(); gm.optimizer.zero_grad(set_to_none=True)
+        gm.xyz_gradient_accum = torch.rand(P, 1, generator=g); gm.denom = (torch.rand(P, 1, generator=g) * 5).floor()
+        cap = gm.capture()
+        out.update({f"ck_init_{k}": v.numpy() for k, v in init.items()})
+        out.update({f"ck_grad_{k}": v.numpy() for k, v in grads.items()})
+        out["ck_len"] = len(cap); out["ck_active_sh_degree"] = cap[0]; out["ck_spatial_lr_scale"] = cap[11]
+        for idx, k in zip(range(1, 7), ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity")):
+            out[f"ck_{idx}_{k}"] = cap[idx].detach().numpy().copy()      # capture() hands out the live tensors
+        out["ck_7_max_radii2D"] = cap[7].numpy().copy(); out["ck_8_xyz_gradient_accum"] = cap[8].numpy().copy(); out["ck_9_denom"] = cap[9].numpy().copy()
+        sd = cap[10]
+        out["ck_opt_groups"] = np.array(json.dumps([{k: v for k, v in gp.items()} for gp in sd["param_groups"]]))
+        for pid, st in sd["state"].items():
+            out[f"ck_opt_state{pid}_step"] = np.array(float(st["step"]))
+            out[f"ck_opt_state{pid}_exp_avg"] = st["exp_avg"].numpy().copy(); out[f"ck_opt_state{pid}_exp_avg_sq"] = st["exp_avg_sq"].numpy().copy()
+        # restore() into a fresh model, one more identical step on both: the states must stay equal (pins restore's order of operations)
+        import copy
+        gm2 = GaussianModel(deg)
+        gm2.restore(copy.deepcopy(cap), opt)                  # as after torch.save / torch.load: restore() itself shares the tensors
+        for m_ in (gm, gm2):
+            m_.update_learning_rate(8)
+            for grp in m_.optimizer.param_groups:
+                grp["params"][0].grad = grads[grp["name"]].clone() * 0.5
+            m_.optimizer.step()
+        assert all(torch.equal(a_, b_) for a_, b_ in zip((gm._xyz, gm._opacity, gm._rotation), (gm2._xyz, gm2._opacity, gm2._rotation)))
+        out.update({f"ck_after_{k}": getattr(gm2, a_).detach().numpy() for k, a_ in
+                    zip(names_, ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"))})
+        out["ck_after_lr_xyz"] = np.array([grp["lr"] for grp in gm2.optimizer.param_groups if grp["name"] == "xyz"][0])
+    finally:
+        torch.zeros, torch.Tensor.cuda, torch.cuda.empty_cache = _zeros, _cuda, _empty_cache
+    np.savez_compressed(os.path.join(a.out, "scene_io.npz"), **out)
+    print("wrote scene_io.npz,", sorted(n for n in os.listdir(a.out) if n.startswith("scene_io")))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden"))
+    ap.add_argument("--only", default="", help="'scene_io': regenerate only the scene_io fixtures")
     a = ap.parse_args()
     sys.path.insert(0, a.ref)
     os.makedirs(a.out, exist_ok=True)
+    if a.only == "scene_io":
+        scene_io_fixtures(a)
+        return
     torch.manual_seed(0)
     rng = np.random.default_rng(0)
 
@@ -218,6 +366,7 @@ def main():
     shutil.copyfile(os.path.join(model_dir, "points3D.ply"), os.path.join(a.out, "table_points3D.ply"))
     # the SfM cloud of tiramisu_ds (33 730 points): BASELINE config 4 names this scene
     shutil.copyfile(os.path.join(a.ref, "tiramisu_ds", "sparse", "0", "points3D.ply"), os.path.join(a.out, "tiramisu_points3D.ply"))
+    scene_io_fixtures(a)
     print("wrote", sorted(os.listdir(a.out)))
 
 

@@ -151,3 +151,109 @@ def test_two_ranks_one_camera_each_allreduce_matches_serial_sum():
     np.testing.assert_array_equal(res[0][3], serial[0][2] + serial[1][2])
     P, M = 400, 4
     assert res[0][4] == 4 * (P * (3 + 3 + 3 * (M - 1) + 1 + 3 + 4) + 2 * P)      # 23 + 2 floats per Gaussian at M = 4
+
+
+# ---- GradientExchange: overlap / buckets / active SH / sparse against the dense blocking sum ----------------------
+def _fake_grads(rank, P, M, seed=0):
+    """Deterministic per-rank 'gradients' with per-rank visibility: rows a rank does not see are exactly zero."""
+    rng = np.random.default_rng(100 * seed + rank)
+    vis = rng.uniform(size=P) < 0.6
+    vis[:3] = False                                     # some rows no rank sees
+    g = rng.normal(size=(P, 3 + 3 * M + 1 + 3 + 4)).astype(np.float32) * vis[:, None]
+    return vis, g
+
+
+def _fill(ex, g, P, M):
+    v = ex.views(ex.arena())
+    off = 0
+    for n, w in (("means3D", 3), ("shs", 3 * M), ("opacities", 1), ("scales", 3), ("rotations", 4)):
+        v[n].reshape(P, -1).copy_(torch.from_numpy(g[:, off:off + w])); off += w
+
+
+def _read(ex, arena, P):
+    v = ex.views(arena)
+    return np.concatenate([v[n].reshape(P, -1).numpy() for n in ex.names], axis=1).copy()
+
+
+def _worker_exchange(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gaussian_transformer_amd.dist import GradientExchange
+        P, M = 257, 4
+        out = {}
+        for algo in ("allreduce", "direct"):
+            # dense, blocking, one piece: the reference result
+            ex = GradientExchange(P, M, "cpu", mode="sync", algo=algo, bucket_bytes=1 << 30)
+            vis, g = _fake_grads(rank, P, M)
+            _fill(ex, g, P, M); a = ex.arenas[0]; ex.launch()
+            out[algo, "dense"] = _read(ex, a, P); out[algo, "dense_bytes"] = ex.bytes_last
+            # small buckets + overlap over three consecutive cameras (double buffering)
+            ex = GradientExchange(P, M, "cpu", mode="overlap", algo=algo, bucket_bytes=1000)
+            res = []
+            for cam in range(3):
+                vis_c, g_c = _fake_grads(rank, P, M, seed=cam)
+                _fill(ex, g_c, P, M); arena = ex.arenas[ex.cur]; ex.launch()
+                res.append(arena)
+                if cam >= 1:
+                    pass                                 # arena of camera cam-1 may still be in flight: only read after wait
+            ex.finish()
+            out[algo, "overlap_cam2"] = _read(ex, res[2], P)
+            out[algo, "overlap_cam0_reused"] = res[0] is res[2]
+            # the same three cameras, blocking
+            ex = GradientExchange(P, M, "cpu", mode="sync", algo=algo, bucket_bytes=1 << 30)
+            vis_c, g_c = _fake_grads(rank, P, M, seed=2)
+            _fill(ex, g_c, P, M); a = ex.arenas[0]; ex.launch()
+            out[algo, "sync_cam2"] = _read(ex, a, P)
+            # sparse: union of the visibility masks, compacted rows
+            ex = GradientExchange(P, M, "cpu", mode="sync", algo=algo, bucket_bytes=4096)
+            _fill(ex, g, P, M); a = ex.arenas[0]; ex.launch(visible=torch.from_numpy(vis))
+            out[algo, "sparse"] = _read(ex, a, P); out[algo, "sparse_bytes"] = ex.bytes_last; out[algo, "union"] = ex.union_rows
+            # active SH degree 0 of M = 4: the other coefficient columns are zero on every rank
+            g0 = g.copy(); g0.reshape(P, -1)[:, 3 + 3:3 + 3 * M] = 0.0
+            ex = GradientExchange(P, M, "cpu", mode="sync", algo=algo); _fill(ex, g0, P, M); a = ex.arenas[0]; ex.launch()
+            out[algo, "sh_dense"] = _read(ex, a, P); full_bytes = ex.bytes_last
+            ex = GradientExchange(P, M, "cpu", mode="sync", algo=algo); ex.sh_active = 1
+            _fill(ex, g0, P, M); a = ex.arenas[0]; ex.launch()
+            out[algo, "sh_active"] = _read(ex, a, P); out[algo, "sh_bytes"] = (ex.bytes_last, full_bytes)
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_gradient_exchange_variants_equal_the_dense_sum(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_exchange, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=240); res[r[0]] = r[1]
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    P, M = 257, 4
+    serial = np.zeros((P, 3 + 3 * M + 8), np.float32)                   # rank-order sum ((g0 + g1) + g2)
+    masks = []
+    for r in range(world):
+        vis, g = _fake_grads(r, P, M); masks.append(vis)
+        serial = (serial + g).astype(np.float32) if r else g.copy()
+    union = np.logical_or.reduce(masks)
+    for algo in ("allreduce", "direct"):
+        for r in range(world):
+            o = res[r]
+            np.testing.assert_allclose(o[algo, "dense"], serial, rtol=1e-5, atol=1e-6)      # a ring adds in another order
+            np.testing.assert_array_equal(o[algo, "dense"], res[0][algo, "dense"])            # every rank holds the same bits
+            exact = algo == "direct" or world == 2      # a ring's summation order depends on where an element sits in
+            same = np.testing.assert_array_equal if exact else (lambda a, b: np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6))
+            same(o[algo, "overlap_cam2"], o[algo, "sync_cam2"])                              # overlap + buckets change no bit ...
+            assert o[algo, "overlap_cam0_reused"]                                             # ... with two arenas reused in turn
+            assert o[algo, "union"] == int(union.sum()) and (o[algo, "sparse"][~union] == 0).all()
+            assert o[algo, "sparse_bytes"] == P + 4 * int(union.sum()) * (3 + 3 * M + 8) < o[algo, "dense_bytes"]
+            same(o[algo, "sh_active"], o[algo, "sh_dense"])
+            assert o[algo, "sh_bytes"][0] == o[algo, "sh_bytes"][1] - 4 * P * 3 * (M - 1)
+            same(o[algo, "sparse"], o[algo, "dense"])    # bitwise with rank-order sums (direct) or two ranks; a ring of three
+                                                         # differs in the last bit only (buffer position decides the order)
+        np.testing.assert_array_equal(res[0]["direct", "dense"], serial)                      # direct = the serial rank-order sum, bitwise
