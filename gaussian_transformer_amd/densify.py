@@ -163,8 +163,10 @@ class DensityController:
         return int(sel.sum())
 
     def densify_and_split(self, grads: torch.Tensor, threshold: float, extent: float, N: int = 2,
-                          generator: Optional[torch.Generator] = None) -> int:
-        """Large Gaussians with a large gradient are replaced by N samples of themselves, 1.6x smaller (:349-371)."""
+                          generator: Optional[torch.Generator] = None, normal_fn: Optional[Callable] = None) -> int:
+        """Large Gaussians with a large gradient are replaced by N samples of themselves, 1.6x smaller (:349-371).
+        normal_fn(stds) -> samples ~ N(0, stds^2) replaces torch.normal when given (e.g. drawn on the host, so that the
+        result does not depend on which device's generator the model sits on)."""
         m = self.model
         P = m._xyz.shape[0]
         padded = torch.zeros((P,), device=m._xyz.device)
@@ -172,7 +174,7 @@ class DensityController:
         sel = self._selected(padded, threshold, extent, large=True)
         scale = m.get_scaling.detach()[sel]
         stds = scale.repeat(N, 1)
-        samples = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=generator)
+        samples = normal_fn(stds) if normal_fn is not None else torch.normal(mean=torch.zeros_like(stds), std=stds, generator=generator)
         R = quaternion_to_rotation(m._rotation.detach()[sel]).repeat(N, 1, 1)
         new = {
             "xyz": torch.bmm(R, samples.unsqueeze(-1)).squeeze(-1) + m._xyz.detach()[sel].repeat(N, 1),
@@ -188,13 +190,13 @@ class DensityController:
         return n_sel
 
     def densify_and_prune(self, max_grad: float, min_opacity: float, extent: float, max_screen_size: Optional[float],
-                          generator: Optional[torch.Generator] = None) -> Dict[str, int]:
+                          generator: Optional[torch.Generator] = None, normal_fn: Optional[Callable] = None) -> Dict[str, int]:
         """:389-403.  Returns how many Gaussians were cloned / split / pruned."""
         m = self.model
         grads = m.xyz_gradient_accum / m.denom
         grads[grads.isnan()] = 0.0
         cloned = self.densify_and_clone(grads, max_grad, extent)
-        split = self.densify_and_split(grads, max_grad, extent, generator=generator)
+        split = self.densify_and_split(grads, max_grad, extent, generator=generator, normal_fn=normal_fn)
         prune = (m.get_opacity.detach() < min_opacity).squeeze(-1)
         if max_screen_size:
             prune = prune | (m.max_radii2D > max_screen_size) | (m.get_scaling.detach().max(dim=1).values > 0.1 * extent)
