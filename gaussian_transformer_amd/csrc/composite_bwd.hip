@@ -21,9 +21,13 @@
 #include "gsr_internal.h"
 
 namespace gsr {
+extern int g_composite_lds_pad;
 
 #define LOG2E 1.4426950408889634f
 #define RED_STRIDE 68
+// LDS per wave: 64 staged records x 3 float4 + the reduction scratch, 9 rows of RED_STRIDE floats (153 float4): 5 520 B, so that
+// 29 waves fit a CU's 160 KB (the kernel is latency-sensitive: 22 waves/CU with a 4 KB scratch cost 9 % at config 3)
+#define BWD_LDS_F4 (64 * 3 + (9 * RED_STRIDE + 3) / 4)
 
 __device__ __forceinline__ int xcd_band_unit(int b, int nblocks_padded) {
     const int chunk = nblocks_padded >> 3;
@@ -62,14 +66,14 @@ __device__ __forceinline__ float fold16(float a, float b) {
 template <int NPX, bool COUNT, bool DET>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, int nblocks_padded, int /*exact_cull*/) {
     constexpr int UNITS_PER_TILE = 4 / NPX;          // waves per tile
-    extern __shared__ __align__(16) float4 stage_dyn[];     // per wave: 64 records x 3 float4, then 16 x 64 floats of reduction scratch
+    extern __shared__ __align__(16) float4 stage_dyn[];     // per wave: 64 records x 3 float4, then 9 x RED_STRIDE floats of reduction scratch
     const int T = a.gridx * a.gridy;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     const int unit = xcd_band_unit(blockIdx.x, nblocks_padded) * wpb + wave;
     const int tile = unit / UNITS_PER_TILE, sub = unit % UNITS_PER_TILE;
     if (tile >= T) return;                            // wave-uniform
     const int tx = tile % a.gridx, ty = tile / a.gridx;
-    float4 *my = stage_dyn + wave * (64 * 3 + 16 * 16);
+    float4 *my = stage_dyn + wave * BWD_LDS_F4;
     float *red = reinterpret_cast<float *>(my + 64 * 3);   // [value 0..8][lane 0..63]
     const float4 *rec4 = reinterpret_cast<const float4 *>(a.rec);
     const uint2 range = a.ranges[tile];
@@ -145,11 +149,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
         uint64_t todo = __ballot(live);
         if (COUNT) { c_staged += cnt; c_visits += __builtin_popcountll(todo); }
         __builtin_amdgcn_wave_barrier();
-        while (todo) {
-            const int j = 63 - __builtin_clzll(todo);
-            todo &= ~(1ull << j);
-            const float4 *mj = my + (uint32_t)j * 3u;
-            const float4 r0 = mj[0], r1 = mj[1], r2 = mj[2];
+        // The splats of the batch are visited back to front.  (Issuing the next record's LDS reads a visit ahead was measured:
+        // no gain here, 10 % slower in the forward kernel -- the waves of a SIMD already cover that latency for each other.)
+        auto visit = [&](const float4 r0, const float4 r1, const float4 r2, const int j) __attribute__((always_inline)) {
             const uint32_t bits = __builtin_amdgcn_readfirstlane(__float_as_uint(r2.z));
             // Per-lane partial sums over this lane's pixels: v0..v2 = sum w * dL/dpixel (colour gradient),
             // v8 = sum s, v3,v4 = sum s*dx, s*dy, v5..v7 = sum s*dx*dx, s*dx*dy, s*dy*dy with s = opacity * G * dL/dalpha
@@ -197,27 +199,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
                     v5 += sx * dx; v6 += sx * dy; v7 += sy * dy;
                 }
             };
-#ifndef GSR_ABL_NOMATH
             uint32_t todo_bits = bits;                // drop blocks whose pixels all stopped before this splat
 #pragma unroll
             for (int q = 0; q < NPX; q++)
                 if (pos >= blk_last[q]) todo_bits &= ~(1u << q);
-#ifdef GSR_BWD_FASTPATH
-            if (todo_bits == (1u << NPX) - 1u) {      // scalar branch: every block needed -> one basic block
 #pragma unroll
-                for (int q = 0; q < NPX; q++) block_body(q);
-            } else
-#endif
-            {
-#pragma unroll
-                for (int q = 0; q < NPX; q++)
-                    if (todo_bits & (1u << q)) block_body(q);
-            }
-#else
-            v0 = r0.x * fx[0]; v8 = r1.y;
-#endif
-#ifndef GSR_ABL_NOREDUCE
-            if (any_ok == 0ull) continue;             // wave-uniform: no pixel of this wave blends the splat
+            for (int q = 0; q < NPX; q++)
+                if (todo_bits & (1u << q)) block_body(q);    // scalar branch per block (a fused all-blocks body: 7 % slower)
+            if (any_ok == 0ull) return;                // wave-uniform: no pixel of this wave blends the splat
             if (COUNT) c_red += 1;
             red[0 * RED_STRIDE + lane] = v0; red[1 * RED_STRIDE + lane] = v1; red[2 * RED_STRIDE + lane] = v2;
             red[3 * RED_STRIDE + lane] = v3; red[4 * RED_STRIDE + lane] = v4; red[5 * RED_STRIDE + lane] = v5;
@@ -232,13 +221,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
             __builtin_amdgcn_wave_barrier();
             sel = dpp_add<0xB1>(sel);   // quad_perm [1,0,3,2]
             sel = dpp_add<0x4E>(sel);   // quad_perm [2,3,0,1]
-            const bool touched = true;
-#else
-            float sel = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7 + v8;
-            const bool touched = true;
-#endif
-#ifndef GSR_ABL_NOATOMIC
-            if (touched && slot >= 0) {
+            if (slot >= 0) {
                 if (DET) {
                     a.det[((size_t)(range.x + pos) * UNITS_PER_TILE + sub) * GSR_ACC_FLOATS + slot] = sel;
                 } else {
@@ -246,9 +229,12 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
                     atomicAdd(a.acc + GSR_ACC_FLOATS * (size_t)g + slot, sel);
                 }
             }
-#else
-            if (touched && slot >= 0 && sel == 123.456f) a.acc[slot] = sel;   // keeps the chain alive, never stores
-#endif
+        };
+        while (todo) {
+            const int j = 63 - __builtin_clzll(todo);
+            todo &= ~(1ull << j);
+            const float4 *mj = my + (uint32_t)j * 3u;
+            visit(mj[0], mj[1], mj[2], j);
         }
     }
     if (COUNT && lane == 0 && a.counters) {
@@ -300,7 +286,7 @@ static hipError_t launch_bwd(const CompositeBwdArgs &a, int exact_cull, int wpb,
     const int units = T * (4 / NPX);
     const int blocks = (units + wpb - 1) / wpb;
     const int padded = (blocks + 7) / 8 * 8;
-    const size_t lds = (size_t)wpb * (64 * 3 + 16 * 16) * sizeof(float4);
+    const size_t lds = (size_t)wpb * BWD_LDS_F4 * sizeof(float4) + (size_t)g_composite_lds_pad;
     if (a.det) {
         hipLaunchKernelGGL((composite_bwd_kernel<NPX, false, true>), dim3(padded), dim3(64 * wpb), lds, s, a, padded, exact_cull);
         hipLaunchKernelGGL(det_reduce_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, 4 / NPX);

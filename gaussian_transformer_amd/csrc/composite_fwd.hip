@@ -18,6 +18,7 @@
 #include "gsr_internal.h"
 
 namespace gsr {
+extern int g_composite_lds_pad;
 
 #define LOG2E 1.4426950408889634f
 
@@ -110,9 +111,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
             const uint32_t pos = (uint32_t)(base + j + 1);
             const StagedConic kc = {r0.z, r0.w, r1.x};
             unsigned long long any_stop = 0ull;       // lanes finishing at this splat
-#pragma unroll
-            for (int q = 0; q < NPX; q++) {
-                if (!(bits & ~blk_done & (1u << q))) continue;    // scalar branch: unreachable or saturated block
+            auto block_body = [&](int q) __attribute__((always_inline)) {
                 const float dx = r0.x - fx[q], dy = r0.y - fy[q];
                 float araw;                                          // the one evaluation both passes share (gsr_device.h)
                 const unsigned long long okm = splat_alpha(splat_power_log2(kc, dx, dy), r1.y, araw);
@@ -134,7 +133,13 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
                     Tr[q] = Tn;
                     last[q] = pos;
                 }
-            }
+            };
+            const uint32_t need = bits & ~blk_done;   // blocks the splat can reach and that still have a live pixel
+            // (one straight-line body for "every block needed" was measured: 25 % slower -- larger code and live ranges buy
+            // nothing, the SIMD's other waves already fill the issue slots)
+#pragma unroll
+            for (int q = 0; q < NPX; q++)
+                if (need & (1u << q)) block_body(q);         // scalar branch: unreachable or saturated block
             if (any_stop != 0ull) {                   // wave-uniform: some pixel finished, maybe a whole block
 #pragma unroll
                 for (int q = 0; q < NPX; q++)
@@ -172,10 +177,10 @@ static hipError_t launch_fwd(const CompositeArgs &a, int exact_cull, int wpb, hi
     const int blocks = (units + wpb - 1) / wpb;
     const int padded = (blocks + 7) / 8 * 8;
     if (a.counters)
-        hipLaunchKernelGGL((composite_fwd_kernel<NPX, true>), dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4), s, a,
+        hipLaunchKernelGGL((composite_fwd_kernel<NPX, true>), dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4) + (size_t)g_composite_lds_pad, s, a,
                            padded, exact_cull);
     else
-        hipLaunchKernelGGL((composite_fwd_kernel<NPX, false>), dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4), s, a,
+        hipLaunchKernelGGL((composite_fwd_kernel<NPX, false>), dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4) + (size_t)g_composite_lds_pad, s, a,
                            padded, exact_cull);
     return hipGetLastError();
 }

@@ -29,6 +29,7 @@ static std::atomic<int> g_wpb{1};              // waves per workgroup of the com
 static std::atomic<int> g_two_level_sort{1};   // 1: depth order first, then per-tile lists; 0: one global sort on tile<<32|depth
 static std::atomic<int> g_tile_lists{1};       // 1: tile_lists.hip (super-tile entries); 0: key emission + rocPRIM sort + range detection
 static std::atomic<int> g_depth_buckets{1};    // 0: rocPRIM radix sort + scan; 1: depth_order.hip when P is large enough; 2: always (tests)
+int g_composite_lds_pad = 0;                    // debug: extra dynamic LDS bytes per compositing workgroup (occupancy experiments)
 static std::atomic<int> g_count_lanes{0};      // 1: instrumented compositing kernels (lane-slot accounting, slower)
 static std::atomic<int> g_deterministic_bwd{0};   // 1: fixed-order reduction of the reverse pass's partial gradients
 #define GSR_DEPTH_BUCKETS_MIN_P 1024           // measured at P = 10 k: 25 us against 48 us for rocPRIM sort + scan + copy-back
@@ -276,6 +277,7 @@ int32_t gsr_set_option(const char *name, int32_t value) {
     if (name && !strcmp(name, "tile_lists")) { g_tile_lists.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "depth_log_map")) { DeviceState &ds = dev_state(); ds.depth_log_map.store(value ? 1 : 0); ds.bucket_fail_p.store(0x7fffffff); return GSR_OK; }
     if (name && !strcmp(name, "count_lanes")) { g_count_lanes.store(value ? 1 : 0); return GSR_OK; }
+    if (name && !strcmp(name, "composite_lds_pad")) { g_composite_lds_pad = value < 0 ? 0 : value; return GSR_OK; }
     if (name && !strcmp(name, "deterministic_bwd")) { g_deterministic_bwd.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "depth_buckets")) {
         if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARGUMENT, "depth_buckets must be 0, 1 or 2");
@@ -522,8 +524,10 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     if (P < 0 || W <= 0 || H <= 0 || R < 0) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: bad sizes");
     if (P == 0) return GSR_OK;
     if (!bg || !means3D || !radii || !viewmatrix || !projmatrix || !dL_dpix || !geom_ws || !img_ws || !bwd_ws ||
-        !dL_dmeans2D || !dL_dopacity || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D)
+        !dL_dmeans2D || !dL_dopacity || !dL_dmeans3D)
         return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: missing input, workspace or gradient buffer");
+    if ((colors_precomp && !dL_dcolors) || (cov3D_precomp && !dL_dcov3D))
+        return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: dL_dcolors / dL_dcov3D required with colors_precomp / cov3D_precomp");
     if ((shs != nullptr) == (colors_precomp != nullptr))
         return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: exactly one of shs / colors_precomp must be given");
     if (((scales != nullptr) && (rotations != nullptr)) == (cov3D_precomp != nullptr) || ((scales != nullptr) != (rotations != nullptr)))

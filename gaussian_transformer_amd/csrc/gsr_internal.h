@@ -194,6 +194,7 @@ hipError_t launch_composite_bwd(const CompositeBwdArgs &a, int npx, int exact_cu
 struct PergaussBwdArgs {
     int P, D, M, W, H;
     int raw_params;
+    int sh_tile;             // set by the launcher: dL/dshs rows leave through the LDS tile (M = 16, aligned, not split)
     const float *shs_rest;
     const float *rec;        // forward record (activated opacity at [5])
     float *dL_dsh_rest;

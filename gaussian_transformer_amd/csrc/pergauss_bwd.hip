@@ -5,10 +5,14 @@
 // once (zeros for culled Gaussians), so no gradient buffer needs a zero-fill.
 // HBM-streaming: reads 64 (accumulator row) + 44 + 12*K bytes, writes 64 + 12*M bytes per
 // Gaussian.  Compiled with -ffp-contract=off to track oracle/gsr_ref.c.
+#include <atomic>
 #include "gsr_device.h"
 #include "gsr_internal.h"
 
 namespace gsr {
+
+#define SH_TILE_ROW 13      // float4 per Gaussian row in the LDS tile: 12 + 1 of padding (52 floats: 16-byte LDS stores of
+                            // eight consecutive rows then start in banks 0, 20, 8, 28, 16, 4, 24, 12 -- conflict-free)
 
 // RAW / SPLIT: fused-step extension (raw parameters / split SH tensors) as separate instantiations, so the
 // reference path keeps its register budget.
@@ -19,6 +23,15 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
     const size_t si = (size_t)i;
     constexpr int K = (D + 1) * (D + 1);
     const bool visible = a.radii[si] > 0;
+    // dL/dshs rows of a whole wave (64 Gaussians x 192 B at M = 16) are contiguous in memory: the lanes put their rows into a
+    // wave-private LDS tile and the wave copies the tile out with 16-byte stores at consecutive addresses (12 x 1 KiB), instead
+    // of 48 dword stores per lane at a 192-byte stride that leave every 128-byte line half written 48 times over.
+    // Wave-uniform: M = 16, not the split layout, 16-byte aligned, every lane of the wave alive.
+    extern __shared__ __align__(16) float4 sh_tile_dyn[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave_first = blockIdx.x * 256 + wave * 64;
+    const bool tile_path = !(SPLIT) && a.sh_tile && wave_first + 64 <= a.P;
+    float4 *tile = sh_tile_dyn + wave * (64 * SH_TILE_ROW);
 
     float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dcol[3] = {0.f, 0.f, 0.f}, dm2[2] = {0.f, 0.f}, dop = 0.f;
@@ -129,7 +142,16 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
                 for (int k = 0; k < K; k++)
 #pragma unroll
                     for (int ax = 0; ax < 3; ax++) ddir[ax] += bg3[k][ax] * c[k * 3 + ch] * gch[ch];
-            if (!(SPLIT)) {
+            if (!(SPLIT) && tile_path) {
+                float row[48];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    row[k * 3 + 0] = k < K ? bas[k] * gch[0] : 0.f; row[k * 3 + 1] = k < K ? bas[k] * gch[1] : 0.f;
+                    row[k * 3 + 2] = k < K ? bas[k] * gch[2] : 0.f;
+                }
+#pragma unroll
+                for (int v = 0; v < 12; v++) tile[lane * SH_TILE_ROW + v] = make_float4(row[4 * v], row[4 * v + 1], row[4 * v + 2], row[4 * v + 3]);
+            } else if (!(SPLIT)) {
 #pragma unroll
                 for (int k = 0; k < K; k++) {
                     out[k * 3 + 0] = bas[k] * gch[0]; out[k * 3 + 1] = bas[k] * gch[1]; out[k * 3 + 2] = bas[k] * gch[2];
@@ -190,7 +212,10 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
             }
         }
     } else if (a.shs) {
-        if (!(SPLIT)) {
+        if (!(SPLIT) && tile_path) {
+#pragma unroll
+            for (int v = 0; v < 12; v++) tile[lane * SH_TILE_ROW + v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (!(SPLIT)) {
             float *out = a.dL_dsh + si * (size_t)a.M * 3;
             for (int k = 0; k < 3 * a.M; k++) out[k] = 0.f;
         } else {
@@ -200,27 +225,58 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
         }
     }
 
+    if (a.shs && tile_path) {            // the wave's 64 rows = 768 consecutive float4 in memory
+        __builtin_amdgcn_wave_barrier();
+        float4 *dst = reinterpret_cast<float4 *>(a.dL_dsh + (size_t)wave_first * 48);
+#pragma unroll
+        for (int t = 0; t < 12; t++) {
+            const int q = t * 64 + lane;
+            const int g = (q * 43691) >> 19;         // q / 12 for q < 768
+            dst[q] = tile[g * SH_TILE_ROW + (q - 12 * g)];
+        }
+    }
     a.dL_dmeans2D[3 * si] = dm2[0]; a.dL_dmeans2D[3 * si + 1] = dm2[1]; a.dL_dmeans2D[3 * si + 2] = 0.f;
     a.dL_dopacity[si] = dop;
-    a.dL_dcolors[3 * si] = dcol[0]; a.dL_dcolors[3 * si + 1] = dcol[1]; a.dL_dcolors[3 * si + 2] = dcol[2];
+    if (a.dL_dcolors) { a.dL_dcolors[3 * si] = dcol[0]; a.dL_dcolors[3 * si + 1] = dcol[1]; a.dL_dcolors[3 * si + 2] = dcol[2]; }
     a.dL_dmeans3D[3 * si] = dmean[0]; a.dL_dmeans3D[3 * si + 1] = dmean[1]; a.dL_dmeans3D[3 * si + 2] = dmean[2];
+    if (a.dL_dcov3D) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * si + k] = dcov[k];
+        for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * si + k] = dcov[k];
+    }
     if (a.dL_dscales) {
         a.dL_dscales[3 * si] = dscale[0]; a.dL_dscales[3 * si + 1] = dscale[1]; a.dL_dscales[3 * si + 2] = dscale[2];
         reinterpret_cast<float4 *>(a.dL_drots)[si] = make_float4(drot[0], drot[1], drot[2], drot[3]);
     }
 }
 
-hipError_t launch_pergauss_bwd(const PergaussBwdArgs &a, hipStream_t s) {
-    if (a.P <= 0) return hipSuccess;
+hipError_t launch_pergauss_bwd(const PergaussBwdArgs &a_in, hipStream_t s) {
+    if (a_in.P <= 0) return hipSuccess;
+    PergaussBwdArgs a = a_in;
     const dim3 grid((a.P + 255) / 256), block(256);
     const int d = a.shs ? a.D : 0;
     const bool raw = a.raw_params != 0, split = a.shs_rest != nullptr;
+    a.sh_tile = (a.shs && !split && a.M == 16 && (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15) == 0) ? 1 : 0;
+    const size_t lds = a.sh_tile ? (size_t)4 * 64 * SH_TILE_ROW * sizeof(float4) : 0;      // 52 KiB per workgroup: 3 workgroups per CU
+    if (lds > 48 * 1024) {
+        static std::atomic<uint64_t> attr_set{0};            // one bit per device (per-device attribute, idempotent)
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!(attr_set.load() & (1ull << (dev & 63)))) {
+            hipError_t e = hipSuccess;
+            const void *fns[] = {(const void *)pergauss_bwd_kernel<0, false, false>, (const void *)pergauss_bwd_kernel<1, false, false>,
+                                 (const void *)pergauss_bwd_kernel<2, false, false>, (const void *)pergauss_bwd_kernel<3, false, false>,
+                                 (const void *)pergauss_bwd_kernel<0, true, false>, (const void *)pergauss_bwd_kernel<1, true, false>,
+                                 (const void *)pergauss_bwd_kernel<2, true, false>, (const void *)pergauss_bwd_kernel<3, true, false>};
+            for (const void *f : fns)
+                if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_set.fetch_or(1ull << (dev & 63));
+        }
+    }
 #define GSR_LAUNCH(DD)                                                                                   \
     do {                                                                                                 \
-        if (!raw && !split) hipLaunchKernelGGL((pergauss_bwd_kernel<DD, false, false>), grid, block, 0, s, a);           \
-        else if (raw && !split) hipLaunchKernelGGL((pergauss_bwd_kernel<DD, true, false>), grid, block, 0, s, a);        \
+        if (!raw && !split) hipLaunchKernelGGL((pergauss_bwd_kernel<DD, false, false>), grid, block, lds, s, a);           \
+        else if (raw && !split) hipLaunchKernelGGL((pergauss_bwd_kernel<DD, true, false>), grid, block, lds, s, a);        \
         else if (!raw && split) hipLaunchKernelGGL((pergauss_bwd_kernel<DD, false, true>), grid, block, 0, s, a);        \
         else hipLaunchKernelGGL((pergauss_bwd_kernel<DD, true, true>), grid, block, 0, s, a);                            \
     } while (0)

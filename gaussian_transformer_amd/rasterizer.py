@@ -144,8 +144,10 @@ class HipBackend:
             g_opacity = out((P, 1))
             g_scales = out((P, 3)) if has_sr else torch.empty((0,), **f32)
             g_rots = out((P, 4)) if has_sr else torch.empty((0,), **f32)
-            g_means2D = torch.empty((P, 3), **f32); g_colors = torch.empty((P, 3), **f32)
-            g_cov3D = torch.empty((P, 6), **f32)
+            g_means2D = torch.empty((P, 3), **f32)
+            # gradients of the inputs that were not given are not written at all (36 B per Gaussian less to store)
+            g_colors = torch.empty((P, 3), **f32) if colors_precomp.numel() else None
+            g_cov3D = torch.empty((P, 6), **f32) if cov3D_precomp.numel() else None
             bg = _f32c(rs.bg, "bg", dev); vm = _f32c(rs.viewmatrix, "viewmatrix", dev)
             pm = _f32c(rs.projmatrix, "projmatrix", dev); cp = _f32c(rs.campos, "campos", dev)
             dL = _f32c(dL_dpix, "grad of rendered image", dev)

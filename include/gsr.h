@@ -99,7 +99,8 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
  *   them (read-only here); radii as returned by the forward.
  *   Every gradient buffer is fully written (no pre-zeroing needed):
  *     dL_dmeans2D [P,3] (x,y = gradient w.r.t. NDC coordinates, z = 0), dL_dopacity [P],
- *     dL_dcolors [P,3], dL_dmeans3D [P,3], dL_dcov3D [P,6],
+ *     dL_dcolors [P,3] (may be NULL when shs is given: nobody reads it then), dL_dmeans3D [P,3],
+ *     dL_dcov3D [P,6] (may be NULL when scales / rotations are given),
  *     dL_dsh [P,M,3] (NULL iff shs NULL), dL_dscales [P,3] / dL_drots [P,4] (NULL iff scales NULL). */
 int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64_t R, int32_t W, int32_t H,
                      const float *bg, const float *means3D, const int32_t *radii, const float *shs,
