@@ -30,6 +30,7 @@ SOURCES = {
     "binning.hip": ["-ffp-contract=off"],     # the tile-row span test must round exactly as in preprocess.hip
     "depth_order.hip": ["-ffp-contract=off"],
     "tile_lists.hip": ["-ffp-contract=off"],      # same tile-row spans as preprocess.hip, bit for bit
+    "supertile_sort.hip": ["-ffp-contract=off"],  # likewise
     # -fno-slp-vectorize: the SLP pass packs pairs of scalar f32 ops into v_pk_* and pays for it in v_mov shuffles and
     # registers (bwd: 86 -> 71 VGPRs, 5 -> 7 waves/SIMD; fwd 178 -> 157 us, bwd 387 -> 352 us at config 3, measured)
     "composite_fwd.hip": ["-fno-slp-vectorize"],

@@ -27,7 +27,8 @@ static std::atomic<int> g_bwd_npx{2};          // 8x8 pixel blocks per wave in t
 static std::atomic<int> g_fwd_npx{2};          // same for the forward compositing kernel
 static std::atomic<int> g_wpb{1};              // waves per workgroup of the compositing kernels (waves are independent)
 static std::atomic<int> g_two_level_sort{1};   // 1: depth order first, then per-tile lists; 0: one global sort on tile<<32|depth
-static std::atomic<int> g_tile_lists{1};       // 1: tile_lists.hip (super-tile entries); 0: key emission + rocPRIM sort + range detection
+static std::atomic<int> g_tile_lists{2};       // 2: supertile_sort.hip (per-super-tile LDS order, no global sort); 1: depth_order.hip + tile_lists.hip
+                                               // (round 1's path, also the fall-back of 2); 0: key emission + rocPRIM sort + range detection
 static std::atomic<int> g_depth_buckets{1};    // 0: rocPRIM radix sort + scan; 1: depth_order.hip when P is large enough; 2: always (tests)
 int g_composite_lds_pad = 0;                    // debug: extra dynamic LDS bytes per compositing workgroup (occupancy experiments)
 static std::atomic<int> g_count_lanes{0};      // 1: instrumented compositing kernels (lane-slot accounting, slower)
@@ -98,6 +99,10 @@ GeomView carve_geom(void *base, int P, size_t scan_tb, size_t dsort_tb) {
     g.perm = (uint32_t *)take(n * sizeof(uint32_t));
     g.depth_sorted = (uint32_t *)take(n * sizeof(uint32_t));
     g.orect = (uint4 *)take(n * sizeof(uint4));
+    g.ss_entries = (uint4 *)take((size_t)GSR_SS_ENT_PER_G * n * sizeof(uint4));
+    // the bin count is an image property the workspace size cannot depend on (gsr_workspace_sizes is asked per (P, W, H) but
+    // carve_geom only sees P): room for GSR_SS_WGCNT_WORDS words; supertile_sort.hip is skipped when nblk * S exceeds it
+    g.ss_wg_cnt = (uint32_t *)take((size_t)GSR_SS_WGCNT_WORDS * sizeof(uint32_t));
     g.tl_mat1 = (uint32_t *)take((size_t)GSR_TL_MAX_S * ((n + GSR_TL_L1 - 1) / GSR_TL_L1) * sizeof(uint32_t));
     g.tl_bin_total = (uint32_t *)take(GSR_TL_MAX_S * sizeof(uint32_t));
     g.scan_temp = take(scan_tb);
@@ -274,7 +279,10 @@ const char *gsr_last_error(void) { return g_err; }
 int32_t gsr_set_option(const char *name, int32_t value) {
     if (name && !strcmp(name, "exact_tile_cull")) { g_exact_cull.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "two_level_sort")) { g_two_level_sort.store(value ? 1 : 0); return GSR_OK; }
-    if (name && !strcmp(name, "tile_lists")) { g_tile_lists.store(value ? 1 : 0); return GSR_OK; }
+    if (name && !strcmp(name, "tile_lists")) {
+        if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARGUMENT, "tile_lists must be 0, 1 or 2");
+        g_tile_lists.store(value); return GSR_OK;
+    }
     if (name && !strcmp(name, "depth_log_map")) { DeviceState &ds = dev_state(); ds.depth_log_map.store(value ? 1 : 0); ds.bucket_fail_p.store(0x7fffffff); return GSR_OK; }
     if (name && !strcmp(name, "count_lanes")) { g_count_lanes.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "composite_lds_pad")) { g_composite_lds_pad = value < 0 ? 0 : value; return GSR_OK; }
@@ -405,12 +413,60 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     tm.mark(1);
     uint32_t n32 = 0, e32 = 0;
     const int two_level = g_two_level_sort.load();
+    const int tl_mode = g_tile_lists.load();
+    DeviceState &ds = dev_state();
+    BinningView b;
+    bool lists_done = false;
+    // ---- default: entries binned per super-tile, every bin ordered in LDS (supertile_sort.hip) ----
+    const SuperSortPlan ssp = super_sort_plan(P, W, H);
+    if (tl_mode == 2 && two_level && !debug && ssp.S <= GSR_SS_MAXS && ssp.chunk <= GSR_SS_MAX_CHUNK &&
+        (size_t)ssp.S * ssp.nblk <= (size_t)GSR_SS_WGCNT_WORDS) {
+        uint32_t h[4] = {1u, 0u, 0u, 0u};
+        ReadbackSlot *sl = acquire_slot();
+        const uint32_t seq = sl ? (g_seq.fetch_add(1) | 0x80000000u) : 0u;
+        if (sl) sl->host[4] = 0u;
+        hipError_t e = launch_super_sort_count(g, P, W, H, pa.exact_cull, sl ? sl->host : nullptr, seq, s);
+        if (e == hipSuccess) e = launch_super_sort_scatter(g, P, W, H, pa.exact_cull, s);     // runs while the host waits for the totals
+        if (e != hipSuccess) { release_slot(sl); return fail(GSR_ERR_HIP, "super-tile lists: %s (%d)", hipGetErrorString(e), (int)e); }
+        tm.mark(2);
+        if (sl && wait_seq(sl, seq)) {
+            h[0] = sl->host[0]; h[1] = sl->host[1]; h[2] = sl->host[2]; h[3] = sl->host[3];
+            release_slot(sl);
+        } else {
+            uint32_t w4[4] = {0u, 0u, 0u, 0u};
+            hipError_t ce = hipMemcpyAsync(w4, g.dord.hdr + DO_OVERFLOW, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+            if (ce == hipSuccess) ce = hipMemcpyAsync(w4 + 1, g.dord.hdr + SS_HDR_MAXBIN, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+            if (ce == hipSuccess) ce = hipStreamSynchronize(s);
+            if (sl) { ds.poll_timeouts.fetch_add(1); release_slot(sl); }
+            if (ce != hipSuccess) return fail(GSR_ERR_HIP, "read N: %s (%d)", hipGetErrorString(ce), (int)ce);
+            h[0] = w4[0]; h[1] = w4[1]; h[2] = w4[2]; h[3] = w4[3];
+        }
+        if (!h[0]) {
+            n32 = h[2]; e32 = h[3];
+            const int64_t N = (int64_t)n32;
+            if (num_rendered) *num_rendered = N;
+            const size_t pl_bytes = align_up((size_t)(N > 0 ? N : 1) * sizeof(uint32_t)) + align_up(4 * (size_t)(N > 0 ? N : 1));   // point_list + contrib
+            char *bin_ptr = (char *)binning_alloc(binning_user, pl_bytes);
+            if (!bin_ptr) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL for %zu bytes (N=%lld)", pl_bytes, (long long)N);
+            b = carve_binning(bin_ptr, N, 0);
+            tm.zero(3); tm.zero(5);
+            tm.mark(4);
+            HIP_TRY(launch_super_sort_expand(g, im, b.point_list, P, W, H, h[1], s), "super-tile lists: order + expand");
+            tm.mark(7);
+            lists_done = true;
+        } else {
+            // a bin beyond the LDS capacity or more entries than the workspace holds: this frame takes round 1's path, which
+            // shares the (now dirty) counter region
+            HIP_TRY(hipMemsetAsync(g.dord.hdr, 0, GSR_DO_ZERO_WORDS * sizeof(uint32_t), s), "reset counters");
+            tm.mark(1);
+        }
+    }
+    if (!lists_done) {
     // whether tile_lists.hip builds the per-tile lists is known up front (image size, options): its level-1 counting
     // is queued before the host waits for N, and the depth order then skips the scan only key emission needs
     const bool want_tile_lists = g_tile_lists.load() != 0 && two_level && tile_list_plan(P, 0, W, H).S <= GSR_TL_MAX_S;
     int P_list = P;                                   // entries of the depth-ordered list (perm / offsets)
     const int dbopt = g_depth_buckets.load();
-    DeviceState &ds = dev_state();
     bool bucketed = dbopt == 2 || (dbopt == 1 && P >= GSR_DEPTH_BUCKETS_MIN_P && P < ds.bucket_fail_p.load());
     if (bucketed) {
         uint32_t h[4] = {1u, 0u, 0u, 0u};
@@ -464,7 +520,6 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     const int64_t E = (int64_t)e32;
     const TileListPlan tlp = tile_list_plan(P, E, W, H);
     const bool tile_lists = want_tile_lists && N > 0;
-    BinningView b;
     TileListView tv;
     if (tile_lists) {             // point_list first (what backward and the debug reader expect), then the entry workspace
         const size_t pl_bytes = align_up((size_t)N * sizeof(uint32_t)) + align_up(4 * (size_t)N);   // point_list + contrib
@@ -499,9 +554,10 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
         if (debug) HIP_TRY(hipStreamSynchronize(s), "tile ranges");
         tm.mark(7);
     }
+    }
     CompositeArgs ca;
     ca.W = W; ca.H = H; ca.gridx = gridx; ca.gridy = gridy; ca.ranges = im.ranges; ca.point_list = b.point_list;
-    ca.contrib = b.contrib; ca.contrib_stride = (size_t)(N > 0 ? N : 1);
+    ca.contrib = b.contrib; ca.contrib_stride = (size_t)(n32 > 0 ? n32 : 1);
     ca.rec = g.rec; ca.bg = bg; ca.final_T = im.final_T; ca.n_contrib = im.n_contrib; ca.out_color = out_color;
     ca.counters = lane_counters(0);
     HIP_TRY(launch_composite_fwd(ca, g_fwd_npx.load(), pa.exact_cull, g_wpb.load(), s), "composite launch");

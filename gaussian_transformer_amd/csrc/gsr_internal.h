@@ -39,6 +39,23 @@ struct DepthOrderView {
     uint64_t *comp;              // [P] (depth bits << 32 | id), grouped by bucket
 };
 
+// ---- supertile_sort.hip: per-tile lists by binning entries per super-tile and ordering every bin in LDS ----
+#define GSR_SS_TILES 4         // super-tile edge in tiles (64 x 64 pixels): 16 tiles = 16 mask bits = the 16 waves of a workgroup
+#define GSR_SS_MAXS 8192       // super-tiles the LDS histograms cover (90 x 90: 5760 x 5760 pixels)
+#define GSR_SS_CAP 7168        // entries one workgroup orders in 70 KB of LDS (two workgroups per CU)
+#define GSR_SS_CAP_BIG 14336   // one workgroup per CU
+#define GSR_SS_MAX_CHUNK 8192  // Gaussians per counting / scatter workgroup, at most (P <= 8 M; beyond that round 1's path runs)
+#define GSR_SS_ENT_PER_G 4     // capacity of the entry array in the geometry workspace, per Gaussian
+#define GSR_SS_WGCNT_WORDS (4 << 20)   // per-(counting workgroup, super-tile) counts: 16 MB (1024 workgroups x 4096 super-tiles)
+enum { SS_HDR_MAXBIN = 7, SS_HDR_N = 8, SS_HDR_E = 9 };   // words of the header next to DO_OVERFLOW (zeroed by preprocess)
+struct SuperSortPlan { int SX, SY, S, chunk, nblk; int64_t ecap; };
+SuperSortPlan super_sort_plan(int P, int W, int H);
+struct SuperSortView {
+    uint32_t *hdr;                       // depth_order.hip's header words (same zeroed region, used by one path at a time)
+    uint32_t *bin_cnt, *bin_pairs, *bin_cur;   // [GSR_SS_MAXS] each, zeroed by preprocess (aliases gpair / gcur)
+    uint32_t *bin_start;                 // [S + 1]
+};
+
 struct GeomView {          // per-Gaussian state, P entries each
     float *rec;            // [P][12]
     float *depth;          // [P]
@@ -52,6 +69,8 @@ struct GeomView {          // per-Gaussian state, P entries each
     uint32_t *perm;        // [P] Gaussian ids in (depth, id) order
     uint32_t *depth_sorted;  // [P] sorted depth bits (by-product of the depth sort)
     uint4 *orect;          // [P] rect[perm[.]]: the same records in depth order (empty rectangle for a Gaussian that emits nothing)
+    uint4 *ss_entries;     // [GSR_SS_ENT_PER_G * P] supertile_sort.hip: (depth bits, id, 16-bit tile mask, -) grouped by super-tile
+    uint32_t *ss_wg_cnt;   // [counting workgroups][S] entries per (workgroup of 4096 Gaussians, super-tile)
     uint32_t *tl_mat1;     // [GSR_TL_MAX_S][ceil(P / 512)] tile_lists.hip level-1 count matrix (filled before N is known)
     uint32_t *tl_bin_total;    // [GSR_TL_MAX_S]
     void *scan_temp;
@@ -143,6 +162,22 @@ hipError_t launch_tile_lists_count(const GeomView &g, int P, const uint32_t *hdr
 hipError_t launch_tile_lists(const GeomView &g, const TileListView &v, const ImageView &im, uint32_t *point_list, int P, int P_list,
                              int64_t E, int W, int H, int exact_cull, hipStream_t s);
 hipError_t launch_ranges(const BinningView &b, const ImageView &im, int64_t N, int T, int two_level, hipStream_t s);
+
+static inline SuperSortView super_sort_view(const GeomView &g) {
+    SuperSortView v;
+    v.hdr = g.dord.hdr;
+    v.bin_cnt = reinterpret_cast<uint32_t *>(g.dord.gpair);                  // 2 x GSR_DO_MAXB zeroed words ...
+    v.bin_pairs = reinterpret_cast<uint32_t *>(g.dord.gpair) + GSR_DO_MAXB;
+    v.bin_cur = g.dord.gcur;                                                 // ... and GSR_DO_MAXB more
+    v.bin_start = g.dord.bstart;
+    return v;
+}
+// count + scan (totals to host_out: {overflow, largest bin, N, E, seq}); scatter (may be queued before the host has the totals);
+// per-super-tile order + expansion into point_list / ranges
+hipError_t launch_super_sort_count(const GeomView &g, int P, int W, int H, int exact_cull, uint32_t *host_out, uint32_t seq, hipStream_t s);
+hipError_t launch_super_sort_scatter(const GeomView &g, int P, int W, int H, int exact_cull, hipStream_t s);
+hipError_t launch_super_sort_expand(const GeomView &g, const ImageView &im, uint32_t *point_list, int P, int W, int H, uint32_t maxbin,
+                                    hipStream_t s);
 
 // lane-slot accounting of one compositing launch (instrumented kernels only; gsr_set_option("count_lanes", 1)).
 // A "block visit" is one evaluation of one splat against one 8x8 pixel block = 64 lane slots; lanes_ok of them

@@ -1,0 +1,525 @@
+// supertile_sort.hip -- per-tile, depth-ordered Gaussian lists (S7 + S8) in four launches, with no global sort at all.
+//
+// Upstream sorts N (tile, depth) keyed pairs; round 1 of this library ordered the P Gaussians by depth first (four
+// launches) and then multi-split them into per-tile lists (six more).  But depth order is only ever needed INSIDE a
+// tile, so the order of operations can be turned around:
+//   1. ss_count    bin the emitting Gaussians by SUPER-TILE (4 x 4 tiles = 64 x 64 pixels): entries per bin, counted in LDS
+//                  per workgroup of 4096 Gaussians, one global atomic per (workgroup, touched bin);
+//   2. ss_scan     one workgroup: bin starts, totals (pairs N, entries E, largest bin) -> pinned host words;
+//   3. ss_scatter  every (Gaussian, super-tile) ENTRY = (depth bits, id, 16-bit tile mask) goes to its bin, in arbitrary
+//                  order (workgroup-aggregated reservations); the mask comes from the per-tile-row ellipse spans that
+//                  preprocess packed into the rect record (large rectangles re-evaluate them);
+//   4. ss_sort_expand   one workgroup per super-tile: its <= 7168 entries are ordered by (depth bits, id) in LDS
+//                  (sub-buckets by depth + rank-by-counting; an in-LDS bitonic network for degenerate depth
+//                  distributions) -- the order depends on the keys only, not on the arrival order of step 3 -- and then
+//                  wave t of the workgroup writes tile t's list: it sweeps the sorted entries 64 at a time, ballots
+//                  the tile's mask bit and appends the selected ids as contiguous runs.  ranges[] fall out of it.
+// Same per-tile lists as a stable sort of the pairs on tile << 32 | depth (ties: ascending id), laid out super-tile-major.
+// A bin larger than the LDS capacity (or more super-tiles than the LDS histograms hold) makes the host take the
+// round-1 path (depth_order.hip + tile_lists.hip) or rocPRIM for that frame.
+#include <atomic>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gsr_device.h"
+#include "gsr_internal.h"
+
+namespace gsr {
+
+#define SS_THREADS 1024
+#define SS_NSUB 512               // depth sub-buckets of one bin
+#define SS_RANK_MAX 96            // largest sub-bucket ordered by rank-by-counting
+
+SuperSortPlan super_sort_plan(int P, int W, int H) {
+    SuperSortPlan p;
+    const int gridx = (W + GSR_TILE - 1) / GSR_TILE, gridy = (H + GSR_TILE - 1) / GSR_TILE;
+    p.SX = (gridx + GSR_SS_TILES - 1) / GSR_SS_TILES;
+    p.SY = (gridy + GSR_SS_TILES - 1) / GSR_SS_TILES;
+    p.S = p.SX * p.SY;
+    const long n = P > 0 ? P : 1;
+    p.chunk = 4 * SS_THREADS;
+    while ((n + p.chunk - 1) / p.chunk > 1024) p.chunk *= 2;
+    p.nblk = (int)((n + p.chunk - 1) / p.chunk);
+    p.ecap = (int64_t)GSR_SS_ENT_PER_G * n;
+    return p;
+}
+
+__device__ __forceinline__ uint32_t ss_wave_sum(uint32_t v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m);
+    return v;
+}
+__device__ __forceinline__ uint32_t ss_wave_max(uint32_t v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, m));
+    return v;
+}
+__device__ __forceinline__ uint32_t ss_wave_min(uint32_t v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, m));
+    return v;
+}
+__device__ __forceinline__ uint32_t ss_wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+struct SsRect { int x0, x1, y0, y1, sx0, sx1, sy0, sy1; };
+__device__ __forceinline__ SsRect ss_rect(uint4 rc, int SX, int SY) {
+    SsRect r;
+    r.x0 = (int)(rc.x & 0xffffu); r.x1 = (int)(rc.x >> 16); r.y0 = (int)(rc.y & 0xffffu); r.y1 = (int)(rc.y >> 16);
+    r.sx0 = r.x0 / GSR_SS_TILES; r.sx1 = min((r.x1 + GSR_SS_TILES - 1) / GSR_SS_TILES, SX);
+    r.sy0 = r.y0 / GSR_SS_TILES; r.sy1 = min((r.y1 + GSR_SS_TILES - 1) / GSR_SS_TILES, SY);
+    return r;
+}
+
+// 16-bit tile mask of one Gaussian inside super-tile (sx, sy): bit (ty & 3) * 4 + (tx & 3) for every tile the ellipse reaches.
+// Small rectangles (sp != ~0): straight from the row spans preprocess packed (byte k = (c0 - x0) | (c1 - x0) << 4 of row y0 + k).
+__device__ __forceinline__ uint32_t ss_mask_small(const SsRect &q, uint64_t sp, int sx, int sy) {
+    uint32_t m = 0u;
+    const int bx = sx * GSR_SS_TILES;
+#pragma unroll
+    for (int k = 0; k < GSR_SS_TILES; k++) {
+        const int ty = sy * GSR_SS_TILES + k, r = ty - q.y0;
+        if (r < 0 || r >= 8 || ty >= q.y1) continue;
+        const uint32_t bb = (uint32_t)(sp >> (8 * r)) & 0xffu;
+        const int c0 = q.x0 + (int)(bb & 15u), c1 = q.x0 + (int)(bb >> 4);
+        const int lo = max(c0, bx) - bx, hi = min(c1, bx + GSR_SS_TILES) - bx;
+        if (hi > lo) m |= (((1u << hi) - 1u) & ~((1u << lo) - 1u)) << (4 * k);
+    }
+    return m;
+}
+
+struct SsBinArgs {
+    int P, chunk, SX, SY, W, H, exact_cull;
+    const uint4 *rect;
+    const uint32_t *tiles, *depth_bits;
+    const float *rec;
+    uint32_t *hdr;
+    uint32_t *bin_cnt;               // [S] global entry counts (count kernel: atomics)
+    uint32_t *wg_cnt;                // [nblk][S] entries of every counting workgroup per bin (count kernel writes, scatter reads)
+    const uint32_t *bin_start;
+    uint32_t *bin_cur, *bin_pairs;
+    uint4 *entries;
+};
+
+// Entries of the workgroup's chunk of Gaussians: f(bin, mask, gaussian, depth bits) for every (super-tile, non-empty mask).
+// Rectangles whose row spans preprocess packed (<= 8 x 15 tiles) are handled by their own lane.  Larger ones -- a few per
+// cent of the Gaussians, up to a thousand tiles each -- would leave 63 lanes waiting for one, so they are deferred to a list
+// in LDS and then taken one per WAVE: the lanes first evaluate the ellipse-vs-tile-row span of 64 tile rows in parallel
+// (exactly as preprocess counted them: same function, same rounding, -ffp-contract=off), then switch to one lane per
+// super-tile of the band and assemble the masks from those spans.
+template <class F>
+__device__ __forceinline__ void ss_for_chunk_entries(const SsBinArgs &a, uint32_t *big /*[chunk]*/, uint32_t *nbig /*LDS, zeroed*/,
+                                                     uint32_t *spans /*[waves][64]*/, F f) {
+    const int i0 = blockIdx.x * a.chunk, i1 = min(a.P, i0 + a.chunk);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int base = i0; base < i1; base += 4 * SS_THREADS) {
+        // four Gaussians per thread, every load issued before the first use
+        uint32_t t[4]; uint4 rc[4]; uint32_t dp[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = base + k * SS_THREADS + (int)threadIdx.x;
+            t[k] = i < i1 ? a.tiles[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = base + k * SS_THREADS + (int)threadIdx.x;
+            rc[k] = make_uint4(0u, 0u, 0u, 0u); dp[k] = 0u;
+            if (t[k]) { rc[k] = a.rect[i]; dp[k] = a.depth_bits[i]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (!t[k]) continue;
+            const int i = base + k * SS_THREADS + (int)threadIdx.x;
+            const uint64_t sp = (uint64_t)rc[k].z | ((uint64_t)rc[k].w << 32);
+            if (sp == ~0ull) { big[atomicAdd(nbig, 1u)] = (uint32_t)i; continue; }      // at most `chunk` of them: the list cannot overflow
+            const SsRect q = ss_rect(rc[k], a.SX, a.SY);
+            for (int sy = q.sy0; sy < q.sy1; sy++)
+                for (int sx = q.sx0; sx < q.sx1; sx++) {
+                    const uint32_t m = ss_mask_small(q, sp, sx, sy);
+                    if (m) f(sy * a.SX + sx, m, (uint32_t)i, dp[k]);
+                }
+        }
+    }
+    __syncthreads();
+    const int nb = (int)*nbig;
+    uint32_t *my_spans = spans + w * 64;
+    for (int k = w; k < nb; k += SS_THREADS / 64) {                 // one wave per large rectangle
+        const int i = (int)big[k];
+        const SsRect q = ss_rect(a.rect[i], a.SX, a.SY);
+        const uint32_t d = a.depth_bits[i];
+        const float4 r0 = reinterpret_cast<const float4 *>(a.rec)[3 * (size_t)i];
+        const float4 r1 = reinterpret_cast<const float4 *>(a.rec)[3 * (size_t)i + 1];
+        const float4 r2 = reinterpret_cast<const float4 *>(a.rec)[3 * (size_t)i + 2];
+        const CullParams cp = make_cull(r0.z, r0.w, r1.x, r2.z);
+        const int nsx = q.sx1 - q.sx0;
+        for (int sy0 = q.sy0; sy0 < q.sy1; sy0 += 16) {              // bands of 16 super rows = 64 tile rows
+            const int ty = sy0 * GSR_SS_TILES + lane;
+            int c0 = 0, c1 = 0;
+            if (ty >= q.y0 && ty < q.y1) {
+                c0 = q.x0; c1 = q.x1;
+                if (a.exact_cull) tile_row_span(cp, r0.x, r0.y, r0.z, r0.w, ty, a.W, a.H, q.x0, q.x1, c0, c1);
+            }
+            __builtin_amdgcn_wave_barrier();
+            my_spans[lane] = (uint32_t)c0 | ((uint32_t)c1 << 16);
+            __builtin_amdgcn_wave_barrier();
+            const int nsy = min(16, q.sy1 - sy0);
+            for (int e = lane; e < nsy * nsx; e += 64) {
+                const int syl = e / nsx, sx = q.sx0 + (e - syl * nsx);
+                const int bx = sx * GSR_SS_TILES;
+                uint32_t m = 0u;
+#pragma unroll
+                for (int r = 0; r < GSR_SS_TILES; r++) {
+                    const uint32_t spn = my_spans[syl * GSR_SS_TILES + r];
+                    const int lo = max((int)(spn & 0xffffu), bx) - bx, hi = min((int)(spn >> 16), bx + GSR_SS_TILES) - bx;
+                    if (hi > lo) m |= (((1u << hi) - 1u) & ~((1u << lo) - 1u)) << (4 * r);
+                }
+                if (m) f((sy0 + syl) * a.SX + sx, m, (uint32_t)i, d);
+            }
+        }
+    }
+}
+
+// ---- 1: exact entry counts: per (workgroup, super-tile) for the scatter pass, per super-tile (global) for the scan ----
+__global__ __launch_bounds__(SS_THREADS) void ss_count_kernel(SsBinArgs a) {
+    extern __shared__ uint32_t sm[];                       // h[S] | big[chunk] | spans[16][64]
+    __shared__ uint32_t s_sum[2][SS_THREADS / 64];
+    __shared__ uint32_t s_nbig;
+    const int S = a.SX * a.SY;
+    uint32_t *h = sm, *big = sm + S, *spans = big + a.chunk;
+    for (int b = threadIdx.x; b < S; b += SS_THREADS) h[b] = 0u;
+    if (threadIdx.x == 0) s_nbig = 0u;
+    __syncthreads();
+    uint32_t pairs = 0, ents = 0;
+    ss_for_chunk_entries(a, big, &s_nbig, spans, [&](int bin, uint32_t m, uint32_t, uint32_t) {
+        atomicAdd(&h[bin], 1u); pairs += (uint32_t)__popc(m); ents++;
+    });
+    pairs = ss_wave_sum(pairs); ents = ss_wave_sum(ents);
+    if ((threadIdx.x & 63) == 0) { s_sum[0][threadIdx.x >> 6] = pairs; s_sum[1][threadIdx.x >> 6] = ents; }
+    __syncthreads();
+    uint32_t *row = a.wg_cnt + (size_t)blockIdx.x * S;
+    for (int b = threadIdx.x; b < S; b += SS_THREADS) {
+        const uint32_t c = h[b];
+        row[b] = c;
+        if (c) atomicAdd(&a.bin_cnt[b], c);
+    }
+    if (threadIdx.x == 0) {
+        uint32_t p = 0, e = 0;
+        for (int k = 0; k < SS_THREADS / 64; k++) { p += s_sum[0][k]; e += s_sum[1][k]; }
+        if (p) atomicAdd(&a.hdr[SS_HDR_N], p);
+        if (e) atomicAdd(&a.hdr[SS_HDR_E], e);
+    }
+}
+
+// ---- 2: one workgroup: exclusive scan of the bin counts, the totals, the overflow verdict; totals to the pinned words ----
+__global__ __launch_bounds__(SS_THREADS) void ss_scan_kernel(int S, uint32_t ecap, const uint32_t *__restrict__ bin_cnt,
+                                                             uint32_t *__restrict__ bin_start, uint32_t *__restrict__ hdr,
+                                                             uint32_t *host_out, uint32_t seq) {
+    __shared__ uint32_t wtot[SS_THREADS / 64], wmax[SS_THREADS / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int per = (S + SS_THREADS - 1) / SS_THREADS;     // consecutive bins per thread (<= 8 for S <= 8192)
+    const int b0 = per * (int)threadIdx.x;
+    uint32_t c[GSR_SS_MAXS / SS_THREADS], sum = 0, mx = 0;
+#pragma unroll
+    for (int q = 0; q < GSR_SS_MAXS / SS_THREADS; q++) {
+        c[q] = (q < per && b0 + q < S) ? bin_cnt[b0 + q] : 0u;
+        sum += c[q]; mx = max(mx, c[q]);
+    }
+    const uint32_t incl = ss_wave_incl_scan(sum, lane);
+    mx = ss_wave_max(mx);
+    if (lane == 63) { wtot[w] = incl; wmax[w] = mx; }
+    __syncthreads();
+    uint32_t ex = incl - sum;
+    for (int k = 0; k < w; k++) ex += wtot[k];
+    {
+        uint32_t run = ex;
+#pragma unroll
+        for (int q = 0; q < GSR_SS_MAXS / SS_THREADS; q++) {
+            if (q < per && b0 + q < S) bin_start[b0 + q] = run;
+            run += c[q];
+        }
+    }
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0, m = 0;
+        for (int k = 0; k < SS_THREADS / 64; k++) { tot += wtot[k]; m = max(m, wmax[k]); }
+        bin_start[S] = tot;
+        const uint32_t over = (m > GSR_SS_CAP_BIG || tot > ecap) ? 1u : 0u;
+        hdr[DO_OVERFLOW] = over; hdr[SS_HDR_MAXBIN] = m;
+        if (host_out) {
+            host_out[0] = over; host_out[1] = m; host_out[2] = hdr[SS_HDR_N]; host_out[3] = tot;
+            __threadfence_system();
+            __hip_atomic_store(&host_out[4], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// ---- 3: entries to their bins (arbitrary order inside a bin; the sort of step 4 only looks at the keys).  The workgroup
+//      knows its exact count per bin from step 1 (same chunk, same code), reserves one run per touched bin and fills it ----
+__global__ __launch_bounds__(SS_THREADS) void ss_scatter_kernel(SsBinArgs a) {
+    extern __shared__ uint32_t sm[];                       // run base[S] | rank[S] | prs[S] | big[chunk] | spans[16][64]
+    __shared__ uint32_t s_nbig;
+    const int S = a.SX * a.SY;
+    if (a.hdr[DO_OVERFLOW]) return;                        // grid-uniform: the host takes another path for this frame
+    uint32_t *basep = sm, *rank = sm + S, *prs = sm + 2 * S, *big = sm + 3 * S, *spans = big + a.chunk;
+    const uint32_t *row = a.wg_cnt + (size_t)blockIdx.x * S;
+    for (int b = threadIdx.x; b < S; b += SS_THREADS) {
+        const uint32_t c = row[b];
+        basep[b] = c ? a.bin_start[b] + atomicAdd(&a.bin_cur[b], c) : 0u;      // this workgroup's run inside the bin
+        rank[b] = 0u; prs[b] = 0u;
+    }
+    if (threadIdx.x == 0) s_nbig = 0u;
+    __syncthreads();
+    ss_for_chunk_entries(a, big, &s_nbig, spans, [&](int bin, uint32_t m, uint32_t id, uint32_t d) {
+        a.entries[basep[bin] + atomicAdd(&rank[bin], 1u)] = make_uint4(d, id, m, 0u);
+        atomicAdd(&prs[bin], (uint32_t)__popc(m));
+    });
+    __syncthreads();
+    for (int b = threadIdx.x; b < S; b += SS_THREADS)
+        if (prs[b]) atomicAdd(&a.bin_pairs[b], prs[b]);
+}
+
+// ---- 4: one workgroup per super-tile: order the bin by (depth bits, id) in LDS, then one wave per tile writes its list ----
+struct SsSortArgs {
+    int S, SX, gridx, gridy;
+    const uint32_t *hdr, *bin_start, *bin_cur, *bin_pairs;
+    const uint4 *entries;
+    uint32_t *point_list;
+    uint2 *ranges;
+};
+template <int CAP>
+__global__ __launch_bounds__(SS_THREADS, CAP <= GSR_SS_CAP ? 8 : 4) void ss_sort_expand_kernel(SsSortArgs a) {
+    constexpr int ITEMS = CAP / SS_THREADS;
+    extern __shared__ uint64_t buf[];                              // [CAP] keys; later: sorted ids (u32) | sorted masks (u16)
+    uint16_t *mbuf = reinterpret_cast<uint16_t *>(buf + CAP);      // [CAP] masks travelling with the keys
+    __shared__ uint32_t start[SS_NSUB + 1], cur[SS_NSUB];
+    __shared__ uint32_t wred[3][SS_THREADS / 64];
+    __shared__ uint32_t s_max, s_kmin, s_kmax, s_before;
+    __shared__ uint32_t tile_cnt[16], tile_start[17];
+    if (a.hdr[DO_OVERFLOW]) return;                                // grid-uniform
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t e0 = a.bin_start[s];
+    const int n = (int)a.bin_cur[s];                               // entries actually written (empty masks were dropped)
+    // pairs of the super-tiles before this one = where its region of point_list starts
+    {
+        uint32_t before = 0;
+        for (int k = tid; k < s; k += SS_THREADS) before += a.bin_pairs[k];
+        before = ss_wave_sum(before);
+        if (lane == 0) wred[0][w] = before;
+    }
+    if (tid <= SS_NSUB) start[tid] = 0u;
+    if (tid == 0) s_max = 0u;
+    // ---- keys into registers, their depth range ----
+    uint64_t key[ITEMS];
+    uint32_t msk[ITEMS];
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+        const int j = tid + q * SS_THREADS;
+        key[q] = ~0ull; msk[q] = 0u;
+        if (j < n) {
+            const uint4 e = a.entries[e0 + j];
+            key[q] = ((uint64_t)e.x << 32) | e.y; msk[q] = e.z;
+            kmin = min(kmin, e.x); kmax = max(kmax, e.x);
+        }
+    }
+    kmin = ss_wave_min(kmin); kmax = ss_wave_max(kmax);
+    if (lane == 0) { wred[1][w] = kmin; wred[2][w] = kmax; }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t b = 0, mn = 0xffffffffu, mx = 0u;
+        for (int k = 0; k < SS_THREADS / 64; k++) { b += wred[0][k]; mn = min(mn, wred[1][k]); mx = max(mx, wred[2][k]); }
+        s_before = b; s_kmin = mn; s_kmax = mx;
+    }
+    __syncthreads();
+    // monotone map of the depth bits onto the sub-buckets: linear in depth over the bin's own range
+    const float dmin = __uint_as_float(s_kmin);
+    const float span = __uint_as_float(s_kmax) - dmin;
+    const float scale = (s_kmax > s_kmin && span > 0.f) ? (float)SS_NSUB / span : 0.f;
+    auto sub_of = [&](uint64_t k) -> uint32_t {
+        const float v = (__uint_as_float((uint32_t)(k >> 32)) - dmin) * scale;
+        const uint32_t f = v > 0.f ? (uint32_t)v : 0u;
+        return f < SS_NSUB ? f : SS_NSUB - 1u;
+    };
+    if (n > 0) {
+        // ---- sub-bucket histogram, exclusive scan, placement ----
+#pragma unroll
+        for (int q = 0; q < ITEMS; q++)
+            if (tid + q * SS_THREADS < n) atomicAdd(&start[sub_of(key[q])], 1u);
+        __syncthreads();
+        {
+            const uint32_t v = tid < SS_NSUB ? start[tid] : 0u;
+            const uint32_t mx = ss_wave_max(v);
+            const uint32_t incl = ss_wave_incl_scan(v, lane);
+            if (lane == 63) { wred[0][w] = incl; atomicMax(&s_max, mx); }
+            __syncthreads();
+            uint32_t ex = incl - v;
+            for (int k = 0; k < w; k++) ex += wred[0][k];
+            if (tid < SS_NSUB) { start[tid] = ex; cur[tid] = ex; }
+            if (tid == SS_NSUB) start[SS_NSUB] = (uint32_t)n;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < ITEMS; q++)
+            if (tid + q * SS_THREADS < n) {
+                const uint32_t pos = atomicAdd(&cur[sub_of(key[q])], 1u);      // arrival order inside the sub-bucket is irrelevant
+                buf[pos] = key[q]; mbuf[pos] = (uint16_t)msk[q];
+            }
+        __syncthreads();
+    }
+    uint32_t *sid = reinterpret_cast<uint32_t *>(buf);                 // sorted ids, aliasing buf once it has been consumed
+    uint16_t *smask = reinterpret_cast<uint16_t *>(sid + CAP);         // sorted masks behind them (6 * CAP <= 8 * CAP bytes)
+    if (n > 0 && s_max <= SS_RANK_MAX) {                               // workgroup-uniform
+        uint32_t rk[ITEMS], id[ITEMS], mm[ITEMS];
+#pragma unroll
+        for (int q = 0; q < ITEMS; q++) {
+            const int j = tid + q * SS_THREADS;
+            rk[q] = 0u; id[q] = 0u; mm[q] = 0u;
+            if (j < n) {
+                const uint64_t me = buf[j];
+                const uint32_t sb = sub_of(me);
+                const uint32_t a0 = start[sb], a1 = start[sb + 1];
+                uint32_t r = a0;
+                for (uint32_t k = a0; k < a1; k++) r += buf[k] < me ? 1u : 0u;
+                rk[q] = r; id[q] = (uint32_t)me; mm[q] = mbuf[j];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < ITEMS; q++)
+            if (tid + q * SS_THREADS < n) { sid[rk[q]] = id[q]; smask[rk[q]] = (uint16_t)mm[q]; }
+    } else if (n > 0) {                                                // degenerate depth distribution: bitonic network on (key, mask)
+        int m = 64;
+        while (m < n) m <<= 1;
+        for (int j = n + tid; j < m; j += SS_THREADS) { buf[j] = ~0ull; mbuf[j] = 0; }
+        __syncthreads();
+        for (int k = 2; k <= m; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (m >> 1); t += SS_THREADS) {
+                    const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int hi = lo + j;
+                    const uint64_t x = buf[lo], y = buf[hi];
+                    const bool up = (lo & k) == 0;
+                    if ((x > y) == up) { buf[lo] = y; buf[hi] = x; const uint16_t mx = mbuf[lo]; mbuf[lo] = mbuf[hi]; mbuf[hi] = mx; }
+                }
+                __syncthreads();
+            }
+        }
+        uint32_t id[ITEMS], mm[ITEMS];
+#pragma unroll
+        for (int q = 0; q < ITEMS; q++) {
+            const int j = tid + q * SS_THREADS;
+            id[q] = j < n ? (uint32_t)buf[j] : 0u; mm[q] = j < n ? mbuf[j] : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < ITEMS; q++)
+            if (tid + q * SS_THREADS < n) { sid[tid + q * SS_THREADS] = id[q]; smask[tid + q * SS_THREADS] = (uint16_t)mm[q]; }
+    }
+    __syncthreads();
+    // ---- expansion: wave t owns tile t of the super-tile (16 waves, 16 tiles) ----
+    const uint32_t bit = 1u << w;
+    uint32_t total = 0;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        const bool has = j < n && (smask[j] & bit);
+        total += (uint32_t)__popcll(__ballot(has));
+    }
+    if (lane == 0) tile_cnt[w] = total;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = s_before;
+        for (int t = 0; t < 16; t++) { tile_start[t] = run; run += tile_cnt[t]; }
+        tile_start[16] = run;
+    }
+    __syncthreads();
+    const uint32_t my_start = tile_start[w];
+    {
+        const int tx = (s % a.SX) * GSR_SS_TILES + (w & 3), ty = (s / a.SX) * GSR_SS_TILES + (w >> 2);
+        if (lane == 0 && tx < a.gridx && ty < a.gridy) a.ranges[ty * a.gridx + tx] = make_uint2(my_start, my_start + total);
+    }
+    uint32_t run = my_start;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        const bool has = j < n && (smask[j] & bit);
+        const unsigned long long bal = __ballot(has);
+        if (has) a.point_list[run + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = sid[j];
+        run += (uint32_t)__popcll(bal);
+    }
+}
+
+static hipError_t ss_set_lds_attr(const void *fn, size_t bytes, std::atomic<uint64_t> &flags) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (flags.load() & bit) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) flags.fetch_or(bit);
+    return e;
+}
+
+static SsBinArgs ss_bin_args(const GeomView &g, const SuperSortPlan &pl, const SuperSortView &v, int P, int W, int H, int exact_cull) {
+    SsBinArgs a;
+    a.P = P; a.chunk = pl.chunk; a.SX = pl.SX; a.SY = pl.SY; a.W = W; a.H = H; a.exact_cull = exact_cull;
+    a.rect = g.rect; a.tiles = g.tiles; a.depth_bits = reinterpret_cast<const uint32_t *>(g.depth); a.rec = g.rec;
+    a.hdr = v.hdr; a.bin_cnt = v.bin_cnt; a.wg_cnt = g.ss_wg_cnt; a.bin_start = v.bin_start; a.bin_cur = v.bin_cur; a.bin_pairs = v.bin_pairs;
+    a.entries = g.ss_entries;
+    return a;
+}
+
+hipError_t launch_super_sort_count(const GeomView &g, int P, int W, int H, int exact_cull, uint32_t *host_out, uint32_t seq, hipStream_t s) {
+    const SuperSortPlan pl = super_sort_plan(P, W, H);
+    const SuperSortView v = super_sort_view(g);
+    static std::atomic<uint64_t> attr{0};
+    const size_t lds = ((size_t)pl.S + pl.chunk + 16 * 64) * sizeof(uint32_t);
+    if (lds > 48 * 1024) {
+        const hipError_t e = ss_set_lds_attr(reinterpret_cast<const void *>(ss_count_kernel), ((size_t)GSR_SS_MAXS + GSR_SS_MAX_CHUNK + 16 * 64) * sizeof(uint32_t), attr);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(ss_count_kernel, dim3(pl.nblk), dim3(SS_THREADS), lds, s, ss_bin_args(g, pl, v, P, W, H, exact_cull));
+    const uint32_t ecap = pl.ecap > 0xffffffffll ? 0xffffffffu : (uint32_t)pl.ecap;
+    hipLaunchKernelGGL(ss_scan_kernel, dim3(1), dim3(SS_THREADS), 0, s, pl.S, ecap, v.bin_cnt, v.bin_start, v.hdr, host_out, seq);
+    return hipGetLastError();
+}
+
+hipError_t launch_super_sort_scatter(const GeomView &g, int P, int W, int H, int exact_cull, hipStream_t s) {
+    const SuperSortPlan pl = super_sort_plan(P, W, H);
+    const SuperSortView v = super_sort_view(g);
+    static std::atomic<uint64_t> attr{0};
+    const size_t lds = ((size_t)3 * pl.S + pl.chunk + 16 * 64) * sizeof(uint32_t);
+    if (lds > 48 * 1024) {
+        const hipError_t e = ss_set_lds_attr(reinterpret_cast<const void *>(ss_scatter_kernel), ((size_t)3 * GSR_SS_MAXS + GSR_SS_MAX_CHUNK + 16 * 64) * sizeof(uint32_t), attr);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(ss_scatter_kernel, dim3(pl.nblk), dim3(SS_THREADS), lds, s, ss_bin_args(g, pl, v, P, W, H, exact_cull));
+    return hipGetLastError();
+}
+
+hipError_t launch_super_sort_expand(const GeomView &g, const ImageView &im, uint32_t *point_list, int P, int W, int H, uint32_t maxbin,
+                                    hipStream_t s) {
+    const SuperSortPlan pl = super_sort_plan(P, W, H);
+    const SuperSortView v = super_sort_view(g);
+    static std::atomic<uint64_t> attr_small{0}, attr_big{0};
+    SsSortArgs a;
+    a.S = pl.S; a.SX = pl.SX; a.gridx = (W + GSR_TILE - 1) / GSR_TILE; a.gridy = (H + GSR_TILE - 1) / GSR_TILE;
+    a.hdr = v.hdr; a.bin_start = v.bin_start; a.bin_cur = v.bin_cur; a.bin_pairs = v.bin_pairs; a.entries = g.ss_entries;
+    a.point_list = point_list; a.ranges = im.ranges;
+    if (maxbin <= GSR_SS_CAP) {
+        const size_t lds = (size_t)GSR_SS_CAP * 10;
+        const hipError_t e = ss_set_lds_attr(reinterpret_cast<const void *>(ss_sort_expand_kernel<GSR_SS_CAP>), lds, attr_small);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(ss_sort_expand_kernel<GSR_SS_CAP>, dim3(pl.S), dim3(SS_THREADS), lds, s, a);
+    } else {
+        const size_t lds = (size_t)GSR_SS_CAP_BIG * 10;
+        const hipError_t e = ss_set_lds_attr(reinterpret_cast<const void *>(ss_sort_expand_kernel<GSR_SS_CAP_BIG>), lds, attr_big);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(ss_sort_expand_kernel<GSR_SS_CAP_BIG>, dim3(pl.S), dim3(SS_THREADS), lds, s, a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace gsr

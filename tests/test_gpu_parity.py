@@ -53,7 +53,26 @@ def upstream_tile_rule():
     _lib.set_option("exact_tile_cull", 1)
 
 
-@pytest.mark.parametrize("two_level", [0, 1, 2])     # 0: one global sort, 1: rocPRIM depth sort + rocPRIM by-tile sort, 2: depth_order.hip + tile_lists.hip
+@pytest.fixture(params=[2, 1], ids=["supertile_sort", "round1_lists"])
+def lists_mode(request):
+    """The two sort-free list builders: 2 = supertile_sort.hip (default), 1 = depth_order.hip + tile_lists.hip (round 1's path, which
+    is also what the default falls back to when a super-tile's bin exceeds the LDS capacity)."""
+    from gaussian_transformer_amd import _lib
+    _lib.set_option("tile_lists", request.param)
+    yield request.param
+    _lib.set_option("tile_lists", 2)
+
+
+@pytest.fixture
+def round1_lists():
+    from gaussian_transformer_amd import _lib
+    _lib.set_option("tile_lists", 1)
+    yield
+    _lib.set_option("tile_lists", 2)
+
+
+# 0: one global sort, 1: rocPRIM depth sort + rocPRIM by-tile sort, 2: depth_order.hip + tile_lists.hip, 3: supertile_sort.hip
+@pytest.mark.parametrize("two_level", [0, 1, 2, 3])
 @pytest.mark.parametrize("kw", [
     dict(P=3000, width=160, height=112, sh_degree=3, s0=0.03, seed=0),
     dict(P=1500, width=100, height=57, sh_degree=1, s0=0.06, seed=1, zmin=0.05, zmax=5.0),   # culled splats, ragged tiles
@@ -64,13 +83,13 @@ def upstream_tile_rule():
 def test_stages_bit_exact_against_oracle(kw, two_level, upstream_tile_rule):
     from gaussian_transformer_amd import _lib
     _lib.set_option("two_level_sort", 1 if two_level else 0)
-    _lib.set_option("tile_lists", 1 if two_level == 2 else 0)
-    _lib.set_option("depth_buckets", 1 if two_level == 2 else 0)
+    _lib.set_option("tile_lists", {0: 0, 1: 0, 2: 1, 3: 2}[two_level])
+    _lib.set_option("depth_buckets", 1 if two_level >= 2 else 0)
     try:
         _check_stages_bit_exact(kw, two_level)
     finally:
         _lib.set_option("two_level_sort", 1)
-        _lib.set_option("tile_lists", 1)
+        _lib.set_option("tile_lists", 2)
         _lib.set_option("depth_buckets", 1)
 
 
@@ -82,9 +101,9 @@ def test_stages_bit_exact_against_oracle(kw, two_level, upstream_tile_rule):
     dict(P=3000, width=8300, height=130, sh_degree=0, s0=0.02, seed=15),         # 65 x 2 super-tiles... still <= 512
     dict(P=3000, width=8300, height=1100, sh_degree=0, s0=0.02, seed=16),        # 585 super-tiles > 512: rocPRIM path
 ])
-def test_tile_lists_bit_exact(kw, upstream_tile_rule):
-    """tile_lists.hip (default path) against the oracle's sorted pair list, per tile, on grids that stress the
-    super-tile geometry; the last case exceeds the LDS lane-mask capacity and must take the sort path by itself."""
+def test_tile_lists_bit_exact(kw, upstream_tile_rule, lists_mode):
+    """Both sort-free list builders against the oracle's sorted pair list, per tile, on grids that stress the super-tile
+    geometry; the last case exceeds round 1's LDS lane-mask capacity (that path must take the sort path by itself)."""
     _check_stages_bit_exact(dict(kw), 2)
 
 
@@ -98,7 +117,7 @@ def test_tile_lists_bit_exact(kw, upstream_tile_rule):
     dict(P=30000, width=160, height=112, sh_degree=0, s0=0.02, seed=9, quantize_z=0.5),      # 17 depths: ties in every bucket
     dict(P=30000, width=160, height=112, sh_degree=0, s0=0.02, seed=10, quantize_z=0.001),   # small tie groups: rank path
 ])
-def test_bucketed_depth_order_bit_exact(kw, upstream_tile_rule):
+def test_bucketed_depth_order_bit_exact(kw, upstream_tile_rule, round1_lists):
     """depth_order.hip forced on for every P (automatic from P = 1024): same sorted pair list as the oracle's one
     stable sort, including exact depth ties (ascending Gaussian id) and degenerate depth distributions."""
     from gaussian_transformer_amd import _lib
@@ -116,7 +135,7 @@ def test_bucketed_depth_order_bit_exact(kw, upstream_tile_rule):
     dict(P=30000, width=160, height=112, sh_degree=0, s0=0.02, seed=9, quantize_z=0.5),
     dict(P=6000, width=160, height=112, sh_degree=0, s0=0.03, seed=7, zmin=4.0, zmax=4.0),
 ])
-def test_depth_order_log_bucket_map_bit_exact(kw, upstream_tile_rule):
+def test_depth_order_log_bucket_map_bit_exact(kw, upstream_tile_rule, round1_lists):
     """The bucket map that is linear in the depth BITS (what the library switches to after an overflow)."""
     from gaussian_transformer_amd import _lib
     _lib.set_option("depth_log_map", 1)
@@ -126,7 +145,7 @@ def test_depth_order_log_bucket_map_bit_exact(kw, upstream_tile_rule):
         _lib.set_option("depth_log_map", 0)
 
 
-def test_depth_outliers_switch_the_bucket_map(upstream_tile_rule):
+def test_depth_outliers_switch_the_bucket_map(upstream_tile_rule, round1_lists):
     """A handful of far outliers stretch the linear depth map until the whole scene shares one bucket: that frame takes
     the rocPRIM path (same lists), the library switches to the log map and the next frame is bucketed again."""
     from gaussian_transformer_amd import _lib
@@ -146,7 +165,7 @@ def test_depth_outliers_switch_the_bucket_map(upstream_tile_rule):
     dict(P=5000, width=3840, height=2160, sh_degree=0, s0=0.01, seed=33, giants=3),       # 510 super-tiles; splats over all of them
     dict(P=2000, width=1920, height=1080, sh_degree=0, s0=0.2, seed=34),                  # every rectangle beyond 8 x 15 tiles
 ])
-def test_tile_list_edge_cases_bit_exact(kw, upstream_tile_rule):
+def test_tile_list_edge_cases_bit_exact(kw, upstream_tile_rule, lists_mode):
     """Forced through depth_order.hip + tile_lists.hip whatever P is: degenerate sizes, and rectangles too large for the
     packed row spans (the level-1 placement then evaluates the ellipse itself, one lane walking hundreds of super-tiles)."""
     from gaussian_transformer_amd import _lib
@@ -157,7 +176,7 @@ def test_tile_list_edge_cases_bit_exact(kw, upstream_tile_rule):
         _lib.set_option("depth_buckets", 1)
 
 
-def test_tile_list_edge_cases_with_exact_culling():
+def test_tile_list_edge_cases_with_exact_culling(lists_mode):
     """Same degenerate scenes in the default mode (exact culling on): image against the oracle, N never above the upstream count."""
     from gaussian_transformer_amd import _lib
     _lib.set_option("depth_buckets", 2)
@@ -311,7 +330,7 @@ def _table_scene(width=1008, height=567):
     return synth.SyntheticScene(cam, xyz, scales, rots, opac, shs, 3, np.zeros(3, np.float32), dL)
 
 
-def test_table_scene_lists_bit_exact(upstream_tile_rule):
+def test_table_scene_lists_bit_exact(upstream_tile_rule, lists_mode):
     """Real SfM depth / footprint distribution through depth_order.hip + tile_lists.hip: same per-tile lists as the oracle."""
     sc = _table_scene()
     S = oracle_scene(sc)
