@@ -10,8 +10,8 @@
 //                  order (workgroup-aggregated reservations); the mask comes from the per-tile-row ellipse spans that
 //                  preprocess packed into the rect record (large rectangles re-evaluate them);
 //   4. ss_sort_expand   one workgroup per super-tile: its <= 7168 entries are ordered by (depth bits, id) in LDS
-//                  (sub-buckets by depth + rank-by-counting; an in-LDS bitonic network for degenerate depth
-//                  distributions) -- the order depends on the keys only, not on the arrival order of step 3 -- and then
+//                  (sub-buckets by log-depth + rank-by-counting inside a sub-bucket) -- the order depends on the keys
+//                  only, not on the arrival order of step 3 -- and then
 //                  wave t of the workgroup writes tile t's list: it sweeps the sorted entries 64 at a time, ballots
 //                  the tile's mask bit and appends the selected ids as contiguous runs.  ranges[] fall out of it.
 // Same per-tile lists as a stable sort of the pairs on tile << 32 | depth (ties: ascending id), laid out super-tile-major.
@@ -28,7 +28,6 @@ namespace gsr {
 
 #define SS_THREADS 1024
 #define SS_NSUB 512               // depth sub-buckets of one bin
-#define SS_RANK_MAX 96            // largest sub-bucket ordered by rank-by-counting
 
 SuperSortPlan super_sort_plan(int P, int W, int H) {
     SuperSortPlan p;
@@ -298,7 +297,7 @@ __global__ __launch_bounds__(SS_THREADS, CAP <= GSR_SS_CAP ? 8 : 4) void ss_sort
     uint16_t *mbuf = reinterpret_cast<uint16_t *>(buf + CAP);      // [CAP] masks travelling with the keys
     __shared__ uint32_t start[SS_NSUB + 1], cur[SS_NSUB];
     __shared__ uint32_t wred[3][SS_THREADS / 64];
-    __shared__ uint32_t s_max, s_kmin, s_kmax, s_before;
+    __shared__ uint32_t s_kmin, s_kmax, s_before;
     __shared__ uint32_t tile_cnt[16], tile_start[17];
     if (a.hdr[DO_OVERFLOW]) return;                                // grid-uniform
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -312,7 +311,6 @@ __global__ __launch_bounds__(SS_THREADS, CAP <= GSR_SS_CAP ? 8 : 4) void ss_sort
         if (lane == 0) wred[0][w] = before;
     }
     if (tid <= SS_NSUB) start[tid] = 0u;
-    if (tid == 0) s_max = 0u;
     // ---- keys into registers, their depth range ----
     uint64_t key[ITEMS];
     uint32_t msk[ITEMS];
@@ -336,14 +334,13 @@ __global__ __launch_bounds__(SS_THREADS, CAP <= GSR_SS_CAP ? 8 : 4) void ss_sort
         s_before = b; s_kmin = mn; s_kmax = mx;
     }
     __syncthreads();
-    // monotone map of the depth bits onto the sub-buckets: linear in depth over the bin's own range
-    const float dmin = __uint_as_float(s_kmin);
-    const float span = __uint_as_float(s_kmax) - dmin;
-    const float scale = (s_kmax > s_kmin && span > 0.f) ? (float)SS_NSUB / span : 0.f;
+    // Monotone map of the depth bits onto the sub-buckets: linear in the BITS of the (positive) depth, i.e. logarithmic in
+    // depth, over the bin's own range, in exact integer arithmetic.  (A map linear in depth collapses when a few splats
+    // right in front of the camera stretch the range: the bulk of the bin then shares a handful of sub-buckets.)
+    const uint32_t kmin0 = s_kmin;
+    const uint64_t kspan = (uint64_t)(s_kmax >= s_kmin ? s_kmax - s_kmin : 0u) + 1ull;
     auto sub_of = [&](uint64_t k) -> uint32_t {
-        const float v = (__uint_as_float((uint32_t)(k >> 32)) - dmin) * scale;
-        const uint32_t f = v > 0.f ? (uint32_t)v : 0u;
-        return f < SS_NSUB ? f : SS_NSUB - 1u;
+        return (uint32_t)(((uint64_t)((uint32_t)(k >> 32) - kmin0) * (uint64_t)SS_NSUB) / kspan);     // < SS_NSUB
     };
     if (n > 0) {
         // ---- sub-bucket histogram, exclusive scan, placement ----
@@ -353,9 +350,8 @@ __global__ __launch_bounds__(SS_THREADS, CAP <= GSR_SS_CAP ? 8 : 4) void ss_sort
         __syncthreads();
         {
             const uint32_t v = tid < SS_NSUB ? start[tid] : 0u;
-            const uint32_t mx = ss_wave_max(v);
             const uint32_t incl = ss_wave_incl_scan(v, lane);
-            if (lane == 63) { wred[0][w] = incl; atomicMax(&s_max, mx); }
+            if (lane == 63) wred[0][w] = incl;
             __syncthreads();
             uint32_t ex = incl - v;
             for (int k = 0; k < w; k++) ex += wred[0][k];
@@ -373,7 +369,10 @@ __global__ __launch_bounds__(SS_THREADS, CAP <= GSR_SS_CAP ? 8 : 4) void ss_sort
     }
     uint32_t *sid = reinterpret_cast<uint32_t *>(buf);                 // sorted ids, aliasing buf once it has been consumed
     uint16_t *smask = reinterpret_cast<uint16_t *>(sid + CAP);         // sorted masks behind them (6 * CAP <= 8 * CAP bytes)
-    if (n > 0 && s_max <= SS_RANK_MAX) {                               // workgroup-uniform
+    if (n > 0) {
+        // The items are grouped by sub-bucket now: the thread that holds position j counts the smaller keys of j's
+        // sub-bucket (keys are unique: depth bits | id).  Correct for any distribution; a bin whose depths all coincide
+        // costs n comparisons per item (slow, never wrong) -- there is no power-of-two network to overflow the LDS.
         uint32_t rk[ITEMS], id[ITEMS], mm[ITEMS];
 #pragma unroll
         for (int q = 0; q < ITEMS; q++) {
@@ -392,33 +391,6 @@ __global__ __launch_bounds__(SS_THREADS, CAP <= GSR_SS_CAP ? 8 : 4) void ss_sort
 #pragma unroll
         for (int q = 0; q < ITEMS; q++)
             if (tid + q * SS_THREADS < n) { sid[rk[q]] = id[q]; smask[rk[q]] = (uint16_t)mm[q]; }
-    } else if (n > 0) {                                                // degenerate depth distribution: bitonic network on (key, mask)
-        int m = 64;
-        while (m < n) m <<= 1;
-        for (int j = n + tid; j < m; j += SS_THREADS) { buf[j] = ~0ull; mbuf[j] = 0; }
-        __syncthreads();
-        for (int k = 2; k <= m; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int t = tid; t < (m >> 1); t += SS_THREADS) {
-                    const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                    const int hi = lo + j;
-                    const uint64_t x = buf[lo], y = buf[hi];
-                    const bool up = (lo & k) == 0;
-                    if ((x > y) == up) { buf[lo] = y; buf[hi] = x; const uint16_t mx = mbuf[lo]; mbuf[lo] = mbuf[hi]; mbuf[hi] = mx; }
-                }
-                __syncthreads();
-            }
-        }
-        uint32_t id[ITEMS], mm[ITEMS];
-#pragma unroll
-        for (int q = 0; q < ITEMS; q++) {
-            const int j = tid + q * SS_THREADS;
-            id[q] = j < n ? (uint32_t)buf[j] : 0u; mm[q] = j < n ? mbuf[j] : 0u;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < ITEMS; q++)
-            if (tid + q * SS_THREADS < n) { sid[tid + q * SS_THREADS] = id[q]; smask[tid + q * SS_THREADS] = (uint16_t)mm[q]; }
     }
     __syncthreads();
     // ---- expansion: wave t owns tile t of the super-tile (16 waves, 16 tiles) ----

@@ -100,6 +100,9 @@ def test_stages_bit_exact_against_oracle(kw, two_level, upstream_tile_rule):
     dict(P=70000, width=640, height=360, sh_degree=0, s0=0.01, seed=14),         # 137 level-1 workgroups, many segments
     dict(P=3000, width=8300, height=130, sh_degree=0, s0=0.02, seed=15),         # 65 x 2 super-tiles... still <= 512
     dict(P=3000, width=8300, height=1100, sh_degree=0, s0=0.02, seed=16),        # 585 super-tiles > 512: rocPRIM path
+    dict(P=6000, width=64, height=64, sh_degree=0, s0=0.5, seed=41, zmin=4.0, zmax=4.0),     # one bin of 6000 entries, ONE depth
+    dict(P=6500, width=64, height=64, sh_degree=0, s0=0.3, seed=42, zmin=0.21, zmax=40.0),   # one bin, depths over 7 octaves
+    dict(P=13000, width=64, height=64, sh_degree=0, s0=0.3, seed=43, zmin=0.21, zmax=40.0),  # 7168 < bin <= 14336: one workgroup per CU
 ])
 def test_tile_lists_bit_exact(kw, upstream_tile_rule, lists_mode):
     """Both sort-free list builders against the oracle's sorted pair list, per tile, on grids that stress the super-tile
