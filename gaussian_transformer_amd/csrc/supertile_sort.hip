@@ -28,6 +28,7 @@ namespace gsr {
 
 #define SS_THREADS 1024
 #define SS_NSUB 512               // depth sub-buckets of one bin
+#define SS_RANK_MAX 96            // largest sub-bucket the depth-linear map may produce before the bit-linear map takes over
 
 SuperSortPlan super_sort_plan(int P, int W, int H) {
     SuperSortPlan p;
@@ -334,20 +335,43 @@ __global__ __launch_bounds__(SS_THREADS, CAP <= GSR_SS_CAP ? 8 : 4) void ss_sort
         s_before = b; s_kmin = mn; s_kmax = mx;
     }
     __syncthreads();
-    // Monotone map of the depth bits onto the sub-buckets: linear in the BITS of the (positive) depth, i.e. logarithmic in
-    // depth, over the bin's own range, in exact integer arithmetic.  (A map linear in depth collapses when a few splats
-    // right in front of the camera stretch the range: the bulk of the bin then shares a handful of sub-buckets.)
+    // Monotone map of the depth bits onto the sub-buckets, over the bin's own range.  First choice: linear in DEPTH, which
+    // spreads a typical bin evenly (rank-by-counting then compares a key with ~10 others).  A few splats right in front of
+    // the camera stretch such a map until the bulk of the bin shares a handful of sub-buckets; when the largest sub-bucket
+    // exceeds SS_RANK_MAX the histogram is redone with a map linear in the depth BITS (logarithmic in depth, exact integer
+    // arithmetic), which no outlier can stretch that way.  Either map is monotone, so the order is the same.
     const uint32_t kmin0 = s_kmin;
     const uint64_t kspan = (uint64_t)(s_kmax >= s_kmin ? s_kmax - s_kmin : 0u) + 1ull;
+    const float dmin = __uint_as_float(s_kmin);
+    const float fspan = __uint_as_float(s_kmax) - dmin;
+    const float fscale = (s_kmax > s_kmin && fspan > 0.f) ? (float)SS_NSUB / fspan : 0.f;
+    bool log_map = false;                                              // workgroup-uniform
     auto sub_of = [&](uint64_t k) -> uint32_t {
-        return (uint32_t)(((uint64_t)((uint32_t)(k >> 32) - kmin0) * (uint64_t)SS_NSUB) / kspan);     // < SS_NSUB
+        const uint32_t kb = (uint32_t)(k >> 32);
+        if (log_map) return (uint32_t)(((uint64_t)(kb - kmin0) * (uint64_t)SS_NSUB) / kspan);     // < SS_NSUB
+        const float v = (__uint_as_float(kb) - dmin) * fscale;
+        const uint32_t f = v > 0.f ? (uint32_t)v : 0u;
+        return f < SS_NSUB ? f : SS_NSUB - 1u;
     };
     if (n > 0) {
-        // ---- sub-bucket histogram, exclusive scan, placement ----
+        // ---- sub-bucket histogram (twice if the linear map turns out lopsided), exclusive scan, placement ----
+        for (int attempt = 0; attempt < 2; attempt++) {
 #pragma unroll
-        for (int q = 0; q < ITEMS; q++)
-            if (tid + q * SS_THREADS < n) atomicAdd(&start[sub_of(key[q])], 1u);
-        __syncthreads();
+            for (int q = 0; q < ITEMS; q++)
+                if (tid + q * SS_THREADS < n) atomicAdd(&start[sub_of(key[q])], 1u);
+            __syncthreads();
+            if (attempt == 1) break;
+            const uint32_t mx = ss_wave_max(tid < SS_NSUB ? start[tid] : 0u);
+            if (lane == 0) wred[1][w] = mx;
+            __syncthreads();
+            uint32_t m = 0;
+            for (int k = 0; k < SS_THREADS / 64; k++) m = max(m, wred[1][k]);
+            if (m <= SS_RANK_MAX) break;                               // workgroup-uniform
+            log_map = true;
+            __syncthreads();
+            if (tid <= SS_NSUB) start[tid] = 0u;
+            __syncthreads();
+        }
         {
             const uint32_t v = tid < SS_NSUB ? start[tid] : 0u;
             const uint32_t incl = ss_wave_incl_scan(v, lane);
