@@ -33,6 +33,7 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (vector)"; re
 # (fma = 2): forward dx,dy 2 + exponent 7 + exp2 1 + opacity*G 1 + cap 1 + alpha*T 1 + T(1-alpha) 1 + 3 colour fma 6;
 # reverse dx,dy 2 + exponent 7 + exp2 1 + opacity*G 1 + cap 1 + (1-alpha) 1 + rcp 1 + T/(1-alpha) 1 + <c,d> - acc 6 +
 # dL/dalpha 3 + acc fma 2 + w 1 + 3 colour fma 6 + s 1 + 9 moment ops 12
+VALU_NS_PER_INST = 1.13          # scripts/valu_rate.hip on an MI355X: v_fma_f32 per SIMD with >= 2 resident waves (profiles/r02/valu_rate.txt)
 FLOP_PER_PAIR = {"fwd.composite": 20, "bwd.composite": 46}
 
 
@@ -253,7 +254,14 @@ def main():
             pmc_stale = pmc.get("kernel_source_sha") != kernel_source_sha()
             if not pmc_stale:
                 traffic = pmc.get(dominant)
-                valu_busy = pmc.get(dominant + ".valu_busy")     # PMC: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles)
+                insts = pmc.get(dominant + ".insts")
+                if insts and dom_ms > 0:
+                    # VALU instructions per SIMD x the fastest vector issue rate measured on this chip (scripts/valu_rate.hip:
+                    # one v_fma_f32 per 1.13 ns per SIMD; cmp/cndmask/DPP are 1.5x and exp/rcp 3x that) / the kernel's time:
+                    # a lower bound on the share of the kernel the vector pipe is issuing
+                    valu_busy = {"insts_per_launch": insts, "simds": 1024, "ns_per_valu_inst": VALU_NS_PER_INST,
+                                 "valu_issue_floor_ms": round(insts["valu"] / 1024 * VALU_NS_PER_INST * 1e-6, 4),
+                                 "frac_of_kernel": round(insts["valu"] / 1024 * VALU_NS_PER_INST * 1e-6 / dom_ms, 4)}
                 pmc_source = f"profiles/pmc_traffic.json (kernel sources {pmc.get('kernel_source_sha')}, {pmc.get('captured', '?')})"
         except Exception:
             traffic = None

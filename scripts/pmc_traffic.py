@@ -4,29 +4,43 @@
 KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is
 exact for 16-B streaming stores and float atomics.  (Gather-type reads are uncalibrated: the doubled
 figure is an upper bound for them.)   usage: pmc_traffic.py <pmc dir> <tag> <out.json>"""
-import csv, glob, json, os, sys, collections
+import csv, glob, json, os, re, sys, collections
 
 d, tag, out = sys.argv[1], sys.argv[2], sys.argv[3]
 STAGES = [("composite_bwd_kernel", "bwd.composite"), ("composite_fwd_kernel", "fwd.composite"),
           ("preprocess_fwd_kernel", "fwd.preprocess"), ("pergauss_bwd_kernel", "bwd.pergauss"),
+          ("ss_sort_expand_kernel", "fwd.sort"), ("ss_count_kernel", "fwd.depth_order+scan"), ("ss_scan_kernel", "fwd.depth_order+scan"),
+          ("ss_scatter_kernel", "fwd.depth_order+scan"),
           ("do_hist_kernel", "fwd.depth_order+scan"), ("do_bucket_scan_kernel", "fwd.depth_order+scan"), ("do_scatter_kernel", "fwd.depth_order+scan"),
           ("do_local_sort_kernel", "fwd.depth_order+scan"), ("tl_", "fwd.sort"),
           ("emit_keys_kernel", "fwd.emit_keys"), ("tile_ranges", "fwd.ranges"), ("scan", "fwd.depth_order+scan"), ("onesweep", "fwd.sort"), ("histogram", "fwd.sort"), ("radix_sort", "fwd.sort"), ("rocprim", "fwd.sort")]
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
-steps = 0
+
+
+def instrumented(name):
+    """bench.py's single lane-counting render runs the <NPX, true, ...> compositing instantiations: not the timed kernels."""
+    return "composite_" in name and re.search(r"kernel<\d+, true", name) is not None
+
+
+import statistics
 for f in sorted(glob.glob(os.path.join(d, f"{tag}_pass*_counter_collection.csv"))):
-    rows = list(csv.DictReader(open(f)))
+    rows = [r for r in csv.DictReader(open(f)) if not instrumented(r["Kernel_Name"])]
     if not rows or rows[0]["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_ATOMIC_sum"):
         continue
     cname = next(r["Counter_Name"] for r in rows if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"))
     n_fwd = sum(1 for r in rows if "composite_fwd_kernel" in r["Kernel_Name"] and r["Counter_Name"] == cname)
     n_bwd = sum(1 for r in rows if "composite_bwd_kernel" in r["Kernel_Name"] and r["Counter_Name"] == cname)
+    per_kernel = collections.defaultdict(list)
     for r in rows:
-        if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
-            continue
+        if r["Counter_Name"] == cname:
+            per_kernel[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    # median per dispatch of each kernel (bench.py's odd renders -- the reference-rule pair count, the instrumented one -- do not
+    # skew it) x its launches per render
+    for name, vals in per_kernel.items():
         for pat, st in STAGES:
-            if pat in r["Kernel_Name"]:
-                tot[st][r["Counter_Name"]] += float(r["Counter_Value"]) / max(n_bwd if st.startswith("bwd.") else n_fwd, 1)
+            if pat in name:
+                per_render = max(1, round(len(vals) / max(n_bwd if st.startswith("bwd.") else n_fwd, 1)))
+                tot[st][cname] += statistics.median(vals) * per_render
                 break
 res = {}
 for st, c in tot.items():
@@ -35,14 +49,17 @@ for st, c in tot.items():
     res[st] = int(rd + wr)
     res[st + ".read"] = int(rd); res[st + ".write"] = int(wr)
 res["per_render_total"] = int(sum(v for k, v in res.items() if isinstance(v, int) and "." in k and k.count(".") == 1))
-# VALU pipe utilisation of the two compositing kernels from the SQ / GRBM passes (scripts/pmc_summary.py's JSON):
-#   busy = SQ_ACTIVE_INST_VALU [quad-cycles] x 4 / (1024 SIMDs x kernel cycles),  kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs
+# instruction counts per launch of the two compositing kernels (scripts/pmc_summary.py's JSON); bench.py prices the VALU count
+# against the issue rate scripts/valu_rate.hip measures (one v_fma_f32 per 1.13 ns per SIMD, 1024 SIMDs) and the live kernel time
 try:
     summ = json.load(open(os.path.join(d, f"{tag}_summary.json")))
     for k, v in summ.items():
+        if instrumented(k):
+            continue
         for pat, st in (("composite_bwd_kernel", "bwd.composite"), ("composite_fwd_kernel", "fwd.composite")):
-            if pat in k and v.get("GRBM_GUI_ACTIVE") and v.get("SQ_ACTIVE_INST_VALU"):
-                res[st + ".valu_busy"] = round(v["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * v["GRBM_GUI_ACTIVE"] / 8.0), 4)
+            if pat in k and v.get("SQ_INSTS_VALU"):
+                res[st + ".insts"] = {"valu": int(v["SQ_INSTS_VALU"]), "salu": int(v.get("SQ_INSTS_SALU", 0)), "lds": int(v.get("SQ_INSTS_LDS", 0)),
+                                      "vmem_rd": int(v.get("SQ_INSTS_VMEM_RD", 0)), "vmem_wr": int(v.get("SQ_INSTS_VMEM_WR", 0)), "waves": int(v.get("SQ_WAVES", 0))}
 except Exception:
     pass
 # tie the figures to the kernels they were measured on: bench.py quotes them only while the native sources are unchanged
