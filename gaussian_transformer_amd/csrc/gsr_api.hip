@@ -99,6 +99,7 @@ GeomView carve_geom(void *base, int P, size_t scan_tb, size_t dsort_tb) {
     g.perm = (uint32_t *)take(n * sizeof(uint32_t));
     g.depth_sorted = (uint32_t *)take(n * sizeof(uint32_t));
     g.orect = (uint4 *)take(n * sizeof(uint4));
+    g.ss_rec = (uint4 *)take(n * sizeof(uint4));
     g.ss_entries = (uint4 *)take((size_t)GSR_SS_ENT_PER_G * n * sizeof(uint4));
     // the bin count is an image property the workspace size cannot depend on (gsr_workspace_sizes is asked per (P, W, H) but
     // carve_geom only sees P): room for GSR_SS_WGCNT_WORDS words; supertile_sort.hip is skipped when nblk * S exceeds it

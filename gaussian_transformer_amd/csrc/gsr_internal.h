@@ -69,6 +69,9 @@ struct GeomView {          // per-Gaussian state, P entries each
     uint32_t *perm;        // [P] Gaussian ids in (depth, id) order
     uint32_t *depth_sorted;  // [P] sorted depth bits (by-product of the depth sort)
     uint4 *orect;          // [P] rect[perm[.]]: the same records in depth order (empty rectangle for a Gaussian that emits nothing)
+    uint4 *ss_rec;         // [P] supertile_sort.hip's view of a Gaussian, written by preprocess: (depth bits, first bin | kind << 30,
+                           //     the 16-bit tile masks of the 2 x 2 super-tiles from that bin); kind 0: emits nothing,
+                           //     1: masks valid, 3: medium (row spans packed in rect), 2: large (rect / rec)
     uint4 *ss_entries;     // [GSR_SS_ENT_PER_G * P] supertile_sort.hip: (depth bits, id, 16-bit tile mask, -) grouped by super-tile
     uint32_t *ss_wg_cnt;   // [counting workgroups][S] entries per (workgroup of 4096 Gaussians, super-tile)
     uint32_t *tl_mat1;     // [GSR_TL_MAX_S][ceil(P / 512)] tile_lists.hip level-1 count matrix (filled before N is known)

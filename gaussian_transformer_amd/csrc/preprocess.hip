@@ -27,6 +27,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
     uint4 rect_out = make_uint4(0u, 0u, ~0u, ~0u);
     uint8_t clamp_out = 0;
     float depth_out = 0.f;
+    uint32_t ss_kind = 0u, ss_bin0 = 0u;       // supertile_sort.hip's record: 0 nothing emitted, 1 the four masks below, 3 row spans in rect, 2 large
+    uint64_t m4 = 0ull;                        // 16-bit tile masks of the 2 x 2 super-tiles under a small rectangle
 
     const float p[3] = {a.means3D[3 * si], a.means3D[3 * si + 1], a.means3D[3 * si + 2]};
     float pv[3];
@@ -83,6 +85,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
                 // the row spans go to tile_lists.hip in one word when the rectangle is small enough
                 const bool small = (y1 - y0) <= 8 && (x1 - x0) <= 15 && (((x1 - 1) >> 3) - (x0 >> 3)) <= 1;
                 uint64_t sp = 0ull;
+                // supertile_sort.hip bins by super-tiles of 4 x 4 tiles: a rectangle inside a 2 x 2 block of them (8 x 8 tiles
+                // from (sbx, sby)) gets its four 16-bit masks here, bit (ty & 3) * 4 + (tx & 3), mask (dy * 2 + dx)
+                const int sbx = x0 & ~(GSR_SS_TILES - 1), sby = y0 & ~(GSR_SS_TILES - 1);
+                const bool small4 = x1 - sbx <= 2 * GSR_SS_TILES && y1 - sby <= 2 * GSR_SS_TILES;
+                uint32_t m4lo = 0u, m4hi = 0u;             // super-tile row 0 / row 1 of the block: mask dx = 0 | mask dx = 1 << 16
+                auto row_masks = [&](int ty, int c0, int c1) {
+                    if (small4 && c1 > c0) {
+                        const int r = ty - sby;
+                        const uint32_t rowbits = ((1u << (c1 - c0)) - 1u) << (c0 - sbx);                       // columns sbx .. sbx + 7
+                        const uint32_t word = ((rowbits & 15u) | ((rowbits >> 4) << 16)) << ((r & 3) * 4);
+                        if (r & 4) m4hi |= word; else m4lo |= word;
+                    }
+                };
                 if (a.exact_cull) {                      // count only the tiles the ellipse can reach
                     tau = cull_tau(opacity);
                     const CullParams cp = make_cull(conA, conB, conC, tau);
@@ -92,11 +107,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
                         tile_row_span(cp, px, py, conA, conB, ty, a.W, a.H, x0, x1, c0, c1);
                         pairs += c1 - c0;
                         sp |= (uint64_t)(uint32_t)((c0 - x0) | ((c1 - x0) << 4)) << (8 * ((ty - y0) & 7));
+                        row_masks(ty, c0, c1);
                     }
                 } else {
-                    for (int k = 0; k < y1 - y0 && k < 8; k++) sp |= (uint64_t)(uint32_t)((x1 - x0) << 4) << (8 * k);
+                    for (int k = 0; k < y1 - y0 && k < 8; k++) {
+                        sp |= (uint64_t)(uint32_t)((x1 - x0) << 4) << (8 * k);
+                        row_masks(y0 + k, x0, x1);
+                    }
                 }
                 if (!small) sp = ~0ull;
+                m4 = (uint64_t)m4lo | ((uint64_t)m4hi << 32);
+                ss_kind = pairs > 0 ? (small4 ? 1u : (small ? 3u : 2u)) : 0u;
+                ss_bin0 = (uint32_t)((y0 / GSR_SS_TILES) * ((a.gridx + GSR_SS_TILES - 1) / GSR_SS_TILES) + x0 / GSR_SS_TILES);
                 float rgb[3];
                 if (a.colors_precomp) {
                     rgb[0] = a.colors_precomp[3 * si]; rgb[1] = a.colors_precomp[3 * si + 1]; rgb[2] = a.colors_precomp[3 * si + 2];
@@ -133,6 +155,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
         a.g.depth[si] = depth_out;
         a.g.opac[si] = r1.y;
         a.g.rect[si] = rect_out;
+        a.g.ss_rec[si] = make_uint4(__float_as_uint(depth_out), ss_bin0 | (ss_kind << 30), (uint32_t)m4, (uint32_t)(m4 >> 32));
         a.g.tiles[si] = tiles_out;
         a.g.clamped[si] = clamp_out;
         a.radii[si] = radius_out;

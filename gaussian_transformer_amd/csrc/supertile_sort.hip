@@ -7,8 +7,8 @@
 //                  per workgroup of 4096 Gaussians, one global atomic per (workgroup, touched bin);
 //   2. ss_scan     one workgroup: bin starts, totals (pairs N, entries E, largest bin) -> pinned host words;
 //   3. ss_scatter  every (Gaussian, super-tile) ENTRY = (depth bits, id, 16-bit tile mask) goes to its bin, in arbitrary
-//                  order (workgroup-aggregated reservations); the mask comes from the per-tile-row ellipse spans that
-//                  preprocess packed into the rect record (large rectangles re-evaluate them);
+//                  order (workgroup-aggregated reservations); preprocess leaves, per Gaussian, the masks of the 2 x 2
+//                  super-tiles under its rectangle (GeomView::ss_rec), larger rectangles re-evaluate their row spans;
 //   4. ss_sort_expand   one workgroup per super-tile: its <= 7168 entries are ordered by (depth bits, id) in LDS
 //                  (sub-buckets by log-depth + rank-by-counting inside a sub-bucket) -- the order depends on the keys
 //                  only, not on the arrival order of step 3 -- and then
@@ -94,10 +94,12 @@ __device__ __forceinline__ uint32_t ss_mask_small(const SsRect &q, uint64_t sp, 
     return m;
 }
 
+
 struct SsBinArgs {
     int P, chunk, SX, SY, W, H, exact_cull;
-    const uint4 *rect;
-    const uint32_t *tiles, *depth_bits;
+    const uint4 *ss_rec;             // per Gaussian: what preprocess prepared for this path (GeomView::ss_rec)
+    const uint4 *rect;               // large rectangles only
+    const uint32_t *depth_bits;
     const float *rec;
     uint32_t *hdr;
     uint32_t *bin_cnt;               // [S] global entry counts (count kernel: atomics)
@@ -108,78 +110,109 @@ struct SsBinArgs {
 };
 
 // Entries of the workgroup's chunk of Gaussians: f(bin, mask, gaussian, depth bits) for every (super-tile, non-empty mask).
-// Rectangles whose row spans preprocess packed (<= 8 x 15 tiles) are handled by their own lane.  Larger ones -- a few per
+// Rectangles inside 2 x 2 super-tiles come with their masks (ss_rec) and are handled by their own lane.  Larger ones -- a few per
 // cent of the Gaussians, up to a thousand tiles each -- would leave 63 lanes waiting for one, so they are deferred to a list
 // in LDS and then taken one per WAVE: the lanes first evaluate the ellipse-vs-tile-row span of 64 tile rows in parallel
 // (exactly as preprocess counted them: same function, same rounding, -ffp-contract=off), then switch to one lane per
 // super-tile of the band and assemble the masks from those spans.
 template <class F>
 __device__ __forceinline__ void ss_for_chunk_entries(const SsBinArgs &a, uint32_t *big /*[chunk]*/, uint32_t *nbig /*LDS, zeroed*/,
-                                                     uint32_t *spans /*[waves][64]*/, F f) {
+                                                     uint32_t *nmid /*LDS, zeroed*/, uint32_t *spans /*[waves][64]*/, F f) {
     const int i0 = blockIdx.x * a.chunk, i1 = min(a.P, i0 + a.chunk);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int base = i0; base < i1; base += 4 * SS_THREADS) {
         // four Gaussians per thread, every load issued before the first use
-        uint32_t t[4]; uint4 rc[4]; uint32_t dp[4];
+        uint4 sr[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int i = base + k * SS_THREADS + (int)threadIdx.x;
-            t[k] = i < i1 ? a.tiles[i] : 0u;
+            sr[k] = i < i1 ? a.ss_rec[i] : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
+            const uint32_t kind = sr[k].y >> 30;
+            if (!kind) continue;
             const int i = base + k * SS_THREADS + (int)threadIdx.x;
-            rc[k] = make_uint4(0u, 0u, 0u, 0u); dp[k] = 0u;
-            if (t[k]) { rc[k] = a.rect[i]; dp[k] = a.depth_bits[i]; }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (!t[k]) continue;
-            const int i = base + k * SS_THREADS + (int)threadIdx.x;
-            const uint64_t sp = (uint64_t)rc[k].z | ((uint64_t)rc[k].w << 32);
-            if (sp == ~0ull) { big[atomicAdd(nbig, 1u)] = (uint32_t)i; continue; }      // at most `chunk` of them: the list cannot overflow
-            const SsRect q = ss_rect(rc[k], a.SX, a.SY);
-            for (int sy = q.sy0; sy < q.sy1; sy++)
-                for (int sx = q.sx0; sx < q.sx1; sx++) {
-                    const uint32_t m = ss_mask_small(q, sp, sx, sy);
-                    if (m) f(sy * a.SX + sx, m, (uint32_t)i, dp[k]);
-                }
+            // deferred: large rectangles from the front of the list, medium ones from its back (at most `chunk` together)
+            if (kind == 2u) { big[atomicAdd(nbig, 1u)] = (uint32_t)i; continue; }
+            if (kind == 3u) { big[a.chunk - 1 - (int)atomicAdd(nmid, 1u)] = (uint32_t)i; continue; }
+            const int bin0 = (int)(sr[k].y & 0x3fffffffu);
+            // the four masks preprocess assembled: super-tiles (dx, dy) of the 2 x 2 block from bin0 (an empty mask where the
+            // block leaves the grid)
+            if (sr[k].z & 0xffffu) f(bin0, sr[k].z & 0xffffu, (uint32_t)i, sr[k].x);
+            if (sr[k].z >> 16) f(bin0 + 1, sr[k].z >> 16, (uint32_t)i, sr[k].x);
+            if (sr[k].w & 0xffffu) f(bin0 + a.SX, sr[k].w & 0xffffu, (uint32_t)i, sr[k].x);
+            if (sr[k].w >> 16) f(bin0 + a.SX + 1, sr[k].w >> 16, (uint32_t)i, sr[k].x);
         }
     }
     __syncthreads();
+    // medium rectangles (row spans packed by preprocess, but more than 2 x 2 super-tiles): one per lane, densely
+    const int nm = (int)*nmid;
+    for (int k = (int)threadIdx.x; k < nm; k += SS_THREADS) {
+        const int i = (int)big[a.chunk - 1 - k];
+        const uint4 rc = a.rect[i];
+        const uint32_t d = a.depth_bits[i];
+        const uint64_t sp = (uint64_t)rc.z | ((uint64_t)rc.w << 32);
+        const SsRect q = ss_rect(rc, a.SX, a.SY);
+        for (int sy = q.sy0; sy < q.sy1; sy++)
+            for (int sx = q.sx0; sx < q.sx1; sx++) {
+                const uint32_t m = ss_mask_small(q, sp, sx, sy);
+                if (m) f(sy * a.SX + sx, m, (uint32_t)i, d);
+            }
+    }
     const int nb = (int)*nbig;
     uint32_t *my_spans = spans + w * 64;
-    for (int k = w; k < nb; k += SS_THREADS / 64) {                 // one wave per large rectangle
-        const int i = (int)big[k];
-        const SsRect q = ss_rect(a.rect[i], a.SX, a.SY);
-        const uint32_t d = a.depth_bits[i];
-        const float4 r0 = reinterpret_cast<const float4 *>(a.rec)[3 * (size_t)i];
-        const float4 r1 = reinterpret_cast<const float4 *>(a.rec)[3 * (size_t)i + 1];
-        const float4 r2 = reinterpret_cast<const float4 *>(a.rec)[3 * (size_t)i + 2];
-        const CullParams cp = make_cull(r0.z, r0.w, r1.x, r2.z);
-        const int nsx = q.sx1 - q.sx0;
-        for (int sy0 = q.sy0; sy0 < q.sy1; sy0 += 16) {              // bands of 16 super rows = 64 tile rows
-            const int ty = sy0 * GSR_SS_TILES + lane;
-            int c0 = 0, c1 = 0;
-            if (ty >= q.y0 && ty < q.y1) {
-                c0 = q.x0; c1 = q.x1;
-                if (a.exact_cull) tile_row_span(cp, r0.x, r0.y, r0.z, r0.w, ty, a.W, a.H, q.x0, q.x1, c0, c1);
-            }
-            __builtin_amdgcn_wave_barrier();
-            my_spans[lane] = (uint32_t)c0 | ((uint32_t)c1 << 16);
-            __builtin_amdgcn_wave_barrier();
-            const int nsy = min(16, q.sy1 - sy0);
-            for (int e = lane; e < nsy * nsx; e += 64) {
-                const int syl = e / nsx, sx = q.sx0 + (e - syl * nsx);
-                const int bx = sx * GSR_SS_TILES;
-                uint32_t m = 0u;
-#pragma unroll
-                for (int r = 0; r < GSR_SS_TILES; r++) {
-                    const uint32_t spn = my_spans[syl * GSR_SS_TILES + r];
-                    const int lo = max((int)(spn & 0xffffu), bx) - bx, hi = min((int)(spn >> 16), bx + GSR_SS_TILES) - bx;
-                    if (hi > lo) m |= (((1u << hi) - 1u) & ~((1u << lo) - 1u)) << (4 * r);
+    // one wave per large rectangle; wave w takes items w, w + 16, ...  Their records are fetched 64 at a time, one item per
+    // lane, and broadcast from that lane when the item's turn comes: one memory latency per 64 items instead of one each
+    constexpr int NW = SS_THREADS / 64;
+    for (int k0 = w; k0 < nb; k0 += NW * 64) {
+        const int kl = k0 + NW * lane;
+        const bool have = kl < nb;
+        const int iv = have ? (int)big[kl] : 0;
+        uint4 rcv = make_uint4(0u, 0u, 0u, 0u);
+        uint32_t dv = 0u;
+        float4 r0v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float conCv = 0.f, tauv = 0.f;
+        if (have) {
+            rcv = a.rect[iv]; dv = a.depth_bits[iv];
+            const float4 *rp = reinterpret_cast<const float4 *>(a.rec) + 3 * (size_t)iv;
+            r0v = rp[0]; conCv = rp[1].x; tauv = rp[2].z;
+        }
+        const int cnt = min(64, (nb - k0 + NW - 1) / NW);               // wave-uniform
+        for (int j = 0; j < cnt; j++) {
+#define SS_BC(x) __builtin_amdgcn_readlane((int)(x), j)
+#define SS_BCF(x) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), j))
+            const int i = SS_BC(iv);
+            const SsRect q = ss_rect(make_uint4((uint32_t)SS_BC(rcv.x), (uint32_t)SS_BC(rcv.y), 0u, 0u), a.SX, a.SY);
+            const uint32_t d = (uint32_t)SS_BC(dv);
+            const float4 r0 = make_float4(SS_BCF(r0v.x), SS_BCF(r0v.y), SS_BCF(r0v.z), SS_BCF(r0v.w));
+            const CullParams cp = make_cull(r0.z, r0.w, SS_BCF(conCv), SS_BCF(tauv));
+#undef SS_BC
+#undef SS_BCF
+            const int nsx = q.sx1 - q.sx0;
+            for (int sy0 = q.sy0; sy0 < q.sy1; sy0 += 16) {              // bands of 16 super rows = 64 tile rows
+                const int ty = sy0 * GSR_SS_TILES + lane;
+                int c0 = 0, c1 = 0;
+                if (ty >= q.y0 && ty < q.y1) {
+                    c0 = q.x0; c1 = q.x1;
+                    if (a.exact_cull) tile_row_span(cp, r0.x, r0.y, r0.z, r0.w, ty, a.W, a.H, q.x0, q.x1, c0, c1);
                 }
-                if (m) f((sy0 + syl) * a.SX + sx, m, (uint32_t)i, d);
+                __builtin_amdgcn_wave_barrier();
+                my_spans[lane] = (uint32_t)c0 | ((uint32_t)c1 << 16);
+                __builtin_amdgcn_wave_barrier();
+                const int nsy = min(16, q.sy1 - sy0);
+                for (int e = lane; e < nsy * nsx; e += 64) {
+                    const int syl = e / nsx, sx = q.sx0 + (e - syl * nsx);
+                    const int bx = sx * GSR_SS_TILES;
+                    uint32_t m = 0u;
+#pragma unroll
+                    for (int r = 0; r < GSR_SS_TILES; r++) {
+                        const uint32_t spn = my_spans[syl * GSR_SS_TILES + r];
+                        const int lo = max((int)(spn & 0xffffu), bx) - bx, hi = min((int)(spn >> 16), bx + GSR_SS_TILES) - bx;
+                        if (hi > lo) m |= (((1u << hi) - 1u) & ~((1u << lo) - 1u)) << (4 * r);
+                    }
+                    if (m) f((sy0 + syl) * a.SX + sx, m, (uint32_t)i, d);
+                }
             }
         }
     }
@@ -189,14 +222,14 @@ __device__ __forceinline__ void ss_for_chunk_entries(const SsBinArgs &a, uint32_
 __global__ __launch_bounds__(SS_THREADS) void ss_count_kernel(SsBinArgs a) {
     extern __shared__ uint32_t sm[];                       // h[S] | big[chunk] | spans[16][64]
     __shared__ uint32_t s_sum[2][SS_THREADS / 64];
-    __shared__ uint32_t s_nbig;
+    __shared__ uint32_t s_nbig, s_nmid;
     const int S = a.SX * a.SY;
     uint32_t *h = sm, *big = sm + S, *spans = big + a.chunk;
     for (int b = threadIdx.x; b < S; b += SS_THREADS) h[b] = 0u;
-    if (threadIdx.x == 0) s_nbig = 0u;
+    if (threadIdx.x == 0) { s_nbig = 0u; s_nmid = 0u; }
     __syncthreads();
     uint32_t pairs = 0, ents = 0;
-    ss_for_chunk_entries(a, big, &s_nbig, spans, [&](int bin, uint32_t m, uint32_t, uint32_t) {
+    ss_for_chunk_entries(a, big, &s_nbig, &s_nmid, spans, [&](int bin, uint32_t m, uint32_t, uint32_t) {
         atomicAdd(&h[bin], 1u); pairs += (uint32_t)__popc(m); ents++;
     });
     pairs = ss_wave_sum(pairs); ents = ss_wave_sum(ents);
@@ -262,7 +295,7 @@ __global__ __launch_bounds__(SS_THREADS) void ss_scan_kernel(int S, uint32_t eca
 //      knows its exact count per bin from step 1 (same chunk, same code), reserves one run per touched bin and fills it ----
 __global__ __launch_bounds__(SS_THREADS) void ss_scatter_kernel(SsBinArgs a) {
     extern __shared__ uint32_t sm[];                       // run base[S] | rank[S] | prs[S] | big[chunk] | spans[16][64]
-    __shared__ uint32_t s_nbig;
+    __shared__ uint32_t s_nbig, s_nmid;
     const int S = a.SX * a.SY;
     if (a.hdr[DO_OVERFLOW]) return;                        // grid-uniform: the host takes another path for this frame
     uint32_t *basep = sm, *rank = sm + S, *prs = sm + 2 * S, *big = sm + 3 * S, *spans = big + a.chunk;
@@ -272,9 +305,9 @@ __global__ __launch_bounds__(SS_THREADS) void ss_scatter_kernel(SsBinArgs a) {
         basep[b] = c ? a.bin_start[b] + atomicAdd(&a.bin_cur[b], c) : 0u;      // this workgroup's run inside the bin
         rank[b] = 0u; prs[b] = 0u;
     }
-    if (threadIdx.x == 0) s_nbig = 0u;
+    if (threadIdx.x == 0) { s_nbig = 0u; s_nmid = 0u; }
     __syncthreads();
-    ss_for_chunk_entries(a, big, &s_nbig, spans, [&](int bin, uint32_t m, uint32_t id, uint32_t d) {
+    ss_for_chunk_entries(a, big, &s_nbig, &s_nmid, spans, [&](int bin, uint32_t m, uint32_t id, uint32_t d) {
         a.entries[basep[bin] + atomicAdd(&rank[bin], 1u)] = make_uint4(d, id, m, 0u);
         atomicAdd(&prs[bin], (uint32_t)__popc(m));
     });
@@ -461,7 +494,7 @@ static hipError_t ss_set_lds_attr(const void *fn, size_t bytes, std::atomic<uint
 static SsBinArgs ss_bin_args(const GeomView &g, const SuperSortPlan &pl, const SuperSortView &v, int P, int W, int H, int exact_cull) {
     SsBinArgs a;
     a.P = P; a.chunk = pl.chunk; a.SX = pl.SX; a.SY = pl.SY; a.W = W; a.H = H; a.exact_cull = exact_cull;
-    a.rect = g.rect; a.tiles = g.tiles; a.depth_bits = reinterpret_cast<const uint32_t *>(g.depth); a.rec = g.rec;
+    a.ss_rec = g.ss_rec; a.rect = g.rect; a.depth_bits = reinterpret_cast<const uint32_t *>(g.depth); a.rec = g.rec;
     a.hdr = v.hdr; a.bin_cnt = v.bin_cnt; a.wg_cnt = g.ss_wg_cnt; a.bin_start = v.bin_start; a.bin_cur = v.bin_cur; a.bin_pairs = v.bin_pairs;
     a.entries = g.ss_entries;
     return a;
