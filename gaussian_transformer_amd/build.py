@@ -25,8 +25,8 @@ ARCH = "gfx950"
 # contraction and use native no-return float atomics.
 SOURCES = {
     "gsr_api.hip": [],
-    "preprocess.hip": ["-ffp-contract=off"],
-    "pergauss_bwd.hip": ["-ffp-contract=off"],
+    "preprocess.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
+    "pergauss_bwd.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "binning.hip": ["-ffp-contract=off"],     # the tile-row span test must round exactly as in preprocess.hip
     "depth_order.hip": ["-ffp-contract=off"],
     "tile_lists.hip": ["-ffp-contract=off"],      # same tile-row spans as preprocess.hip, bit for bit

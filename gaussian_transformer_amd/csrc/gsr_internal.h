@@ -45,6 +45,7 @@ struct DepthOrderView {
 #define GSR_SS_CAP 7168        // entries one workgroup orders in 70 KB of LDS (two workgroups per CU)
 #define GSR_SS_CAP_BIG 14336   // one workgroup per CU
 #define GSR_SS_MAX_CHUNK 8192  // Gaussians per counting / scatter workgroup, at most (P <= 8 M; beyond that round 1's path runs)
+#define GSR_SS_MIDCAP 1024     // medium rectangles one counting / scatter workgroup keeps as records in LDS (more: handled in place)
 #define GSR_SS_ENT_PER_G 4     // capacity of the entry array in the geometry workspace, per Gaussian
 #define GSR_SS_WGCNT_WORDS (4 << 20)   // per-(counting workgroup, super-tile) counts: 16 MB (1024 workgroups x 4096 super-tiles)
 enum { SS_HDR_MAXBIN = 7, SS_HDR_N = 8, SS_HDR_E = 9 };   // words of the header next to DO_OVERFLOW (zeroed by preprocess)
@@ -69,9 +70,11 @@ struct GeomView {          // per-Gaussian state, P entries each
     uint32_t *perm;        // [P] Gaussian ids in (depth, id) order
     uint32_t *depth_sorted;  // [P] sorted depth bits (by-product of the depth sort)
     uint4 *orect;          // [P] rect[perm[.]]: the same records in depth order (empty rectangle for a Gaussian that emits nothing)
-    uint4 *ss_rec;         // [P] supertile_sort.hip's view of a Gaussian, written by preprocess: (depth bits, first bin | kind << 30,
-                           //     the 16-bit tile masks of the 2 x 2 super-tiles from that bin); kind 0: emits nothing,
-                           //     1: masks valid, 3: medium (row spans packed in rect), 2: large (rect / rec)
+    uint4 *ss_rec;         // [P] supertile_sort.hip's view of a Gaussian, written by preprocess: x = depth bits,
+                           //     y = first bin (18 bits) | x0 & 3 << 18 | y0 & 3 << 20 | rows - 1 << 22 | cols - 1 << 25 | kind << 29,
+                           //     kind 0: emits nothing; 1: zw = the 16-bit tile masks of the 2 x 2 super-tiles from that bin;
+                           //     3: <= 8 rows x <= 15 columns: zw = row spans, byte k = (c0 - x0) | (c1 - x0) << 4 of row y0 + k;
+                           //     2: larger rectangle (spans re-evaluated from rect / rec)
     uint4 *ss_entries;     // [GSR_SS_ENT_PER_G * P] supertile_sort.hip: (depth bits, id, 16-bit tile mask, -) grouped by super-tile
     uint32_t *ss_wg_cnt;   // [counting workgroups][S] entries per (workgroup of 4096 Gaussians, super-tile)
     uint32_t *tl_mat1;     // [GSR_TL_MAX_S][ceil(P / 512)] tile_lists.hip level-1 count matrix (filled before N is known)

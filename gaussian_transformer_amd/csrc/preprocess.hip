@@ -27,8 +27,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
     uint4 rect_out = make_uint4(0u, 0u, ~0u, ~0u);
     uint8_t clamp_out = 0;
     float depth_out = 0.f;
-    uint32_t ss_kind = 0u, ss_bin0 = 0u;       // supertile_sort.hip's record: 0 nothing emitted, 1 the four masks below, 3 row spans in rect, 2 large
-    uint64_t m4 = 0ull;                        // 16-bit tile masks of the 2 x 2 super-tiles under a small rectangle
+    uint32_t ss_y = 0u;                        // supertile_sort.hip's record (GeomView::ss_rec): kind 0, nothing emitted
+    uint64_t ss_w = 0ull;
 
     const float p[3] = {a.means3D[3 * si], a.means3D[3 * si + 1], a.means3D[3 * si + 2]};
     float pv[3];
@@ -115,10 +115,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
                         row_masks(y0 + k, x0, x1);
                     }
                 }
+                {   // kind 1: the four masks; kind 3: <= 8 rows x <= 15 columns, the row spans travel in the record together with the
+                    // rectangle's offset inside its first super-tile and its size; kind 2: larger (supertile_sort.hip reads rect / rec)
+                    const bool mid = y1 - y0 <= 8 && x1 - x0 <= 15;
+                    const uint32_t kind = pairs > 0 ? (small4 ? 1u : (mid ? 3u : 2u)) : 0u;
+                    const uint32_t bin0 = (uint32_t)((y0 / GSR_SS_TILES) * ((a.gridx + GSR_SS_TILES - 1) / GSR_SS_TILES) + x0 / GSR_SS_TILES);
+                    ss_y = (bin0 & 0x3ffffu) | ((uint32_t)(x0 & 3) << 18) | ((uint32_t)(y0 & 3) << 20) | ((uint32_t)((y1 - y0 - 1) & 7) << 22) |
+                           ((uint32_t)((x1 - x0 - 1) & 15) << 25) | (kind << 29);
+                    ss_w = small4 ? ((uint64_t)m4lo | ((uint64_t)m4hi << 32)) : sp;
+                }
                 if (!small) sp = ~0ull;
-                m4 = (uint64_t)m4lo | ((uint64_t)m4hi << 32);
-                ss_kind = pairs > 0 ? (small4 ? 1u : (small ? 3u : 2u)) : 0u;
-                ss_bin0 = (uint32_t)((y0 / GSR_SS_TILES) * ((a.gridx + GSR_SS_TILES - 1) / GSR_SS_TILES) + x0 / GSR_SS_TILES);
                 float rgb[3];
                 if (a.colors_precomp) {
                     rgb[0] = a.colors_precomp[3 * si]; rgb[1] = a.colors_precomp[3 * si + 1]; rgb[2] = a.colors_precomp[3 * si + 2];
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
         a.g.depth[si] = depth_out;
         a.g.opac[si] = r1.y;
         a.g.rect[si] = rect_out;
-        a.g.ss_rec[si] = make_uint4(__float_as_uint(depth_out), ss_bin0 | (ss_kind << 30), (uint32_t)m4, (uint32_t)(m4 >> 32));
+        a.g.ss_rec[si] = make_uint4(__float_as_uint(depth_out), ss_y, (uint32_t)ss_w, (uint32_t)(ss_w >> 32));
         a.g.tiles[si] = tiles_out;
         a.g.clamped[si] = clamp_out;
         a.radii[si] = radius_out;

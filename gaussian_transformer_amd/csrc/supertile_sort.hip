@@ -77,24 +77,6 @@ __device__ __forceinline__ SsRect ss_rect(uint4 rc, int SX, int SY) {
     return r;
 }
 
-// 16-bit tile mask of one Gaussian inside super-tile (sx, sy): bit (ty & 3) * 4 + (tx & 3) for every tile the ellipse reaches.
-// Small rectangles (sp != ~0): straight from the row spans preprocess packed (byte k = (c0 - x0) | (c1 - x0) << 4 of row y0 + k).
-__device__ __forceinline__ uint32_t ss_mask_small(const SsRect &q, uint64_t sp, int sx, int sy) {
-    uint32_t m = 0u;
-    const int bx = sx * GSR_SS_TILES;
-#pragma unroll
-    for (int k = 0; k < GSR_SS_TILES; k++) {
-        const int ty = sy * GSR_SS_TILES + k, r = ty - q.y0;
-        if (r < 0 || r >= 8 || ty >= q.y1) continue;
-        const uint32_t bb = (uint32_t)(sp >> (8 * r)) & 0xffu;
-        const int c0 = q.x0 + (int)(bb & 15u), c1 = q.x0 + (int)(bb >> 4);
-        const int lo = max(c0, bx) - bx, hi = min(c1, bx + GSR_SS_TILES) - bx;
-        if (hi > lo) m |= (((1u << hi) - 1u) & ~((1u << lo) - 1u)) << (4 * k);
-    }
-    return m;
-}
-
-
 struct SsBinArgs {
     int P, chunk, SX, SY, W, H, exact_cull;
     const uint4 *ss_rec;             // per Gaussian: what preprocess prepared for this path (GeomView::ss_rec)
@@ -110,14 +92,58 @@ struct SsBinArgs {
 };
 
 // Entries of the workgroup's chunk of Gaussians: f(bin, mask, gaussian, depth bits) for every (super-tile, non-empty mask).
-// Rectangles inside 2 x 2 super-tiles come with their masks (ss_rec) and are handled by their own lane.  Larger ones -- a few per
-// cent of the Gaussians, up to a thousand tiles each -- would leave 63 lanes waiting for one, so they are deferred to a list
-// in LDS and then taken one per WAVE: the lanes first evaluate the ellipse-vs-tile-row span of 64 tile rows in parallel
-// (exactly as preprocess counted them: same function, same rounding, -ffp-contract=off), then switch to one lane per
-// super-tile of the band and assemble the masks from those spans.
+// preprocess left one 16-byte record per Gaussian (GeomView::ss_rec):
+//   kind 1  rectangle inside 2 x 2 super-tiles: the four masks are in the record, the lane emits them;
+//   kind 3  up to 8 x 15 tiles: the row spans are in the record.  Assembling up to 15 masks from them in place would leave the
+//           other lanes of the wave waiting, so the record goes to a list in LDS and the list is worked off one item per lane;
+//   kind 2  larger (about 1 % of the Gaussians, up to a thousand tiles each): deferred to a second list and taken one per WAVE:
+//           the lanes first evaluate the ellipse-vs-tile-row span of 64 tile rows in parallel (exactly as preprocess counted
+//           them: same function, same rounding, -ffp-contract=off), then switch to one lane per super-tile of the band and
+//           assemble the masks from those spans.  Their rect / rec loads are issued before the kind-3 list is worked off.
+struct SsLds {
+    uint4 *midrec;        // [GSR_SS_MIDCAP] kind-3 records
+    uint32_t *midid;      // [GSR_SS_MIDCAP] their Gaussian ids
+    uint32_t *big;        // [chunk] ids of kind-2 Gaussians
+    uint32_t *spans;      // [waves][64]
+    uint32_t *nbig, *nmid;   // zeroed
+};
+#define SS_LDS_LIST_WORDS(chunk) (5 * GSR_SS_MIDCAP + (chunk) + (SS_THREADS / 64) * 64)
+__device__ __forceinline__ SsLds ss_carve_lds(uint32_t *sm, int chunk, uint32_t *nbig, uint32_t *nmid) {
+    SsLds l;
+    l.midrec = reinterpret_cast<uint4 *>(sm);
+    l.midid = sm + 4 * GSR_SS_MIDCAP;
+    l.big = l.midid + GSR_SS_MIDCAP;
+    l.spans = l.big + chunk;
+    l.nbig = nbig; l.nmid = nmid;
+    return l;
+}
+
 template <class F>
-__device__ __forceinline__ void ss_for_chunk_entries(const SsBinArgs &a, uint32_t *big /*[chunk]*/, uint32_t *nbig /*LDS, zeroed*/,
-                                                     uint32_t *nmid /*LDS, zeroed*/, uint32_t *spans /*[waves][64]*/, F f) {
+__device__ __forceinline__ void ss_mid_item(const uint4 sr, uint32_t id, int SX, F f) {
+    const uint32_t y = sr.y;
+    const int bin0 = (int)(y & 0x3ffffu), lx0 = (int)((y >> 18) & 3u), ly0 = (int)((y >> 20) & 3u);
+    const int rows = (int)((y >> 22) & 7u) + 1, cols = (int)((y >> 25) & 15u) + 1;
+    const uint64_t sp = (uint64_t)sr.z | ((uint64_t)sr.w << 32);
+    const int ndx = (lx0 + cols + GSR_SS_TILES - 1) / GSR_SS_TILES, ndy = (ly0 + rows + GSR_SS_TILES - 1) / GSR_SS_TILES;
+    for (int dy = 0; dy < ndy; dy++)
+        for (int dx = 0; dx < ndx; dx++) {
+            uint32_t m = 0u;
+            const int bx = dx * GSR_SS_TILES;                         // tile columns relative to the first super-tile
+#pragma unroll
+            for (int k = 0; k < GSR_SS_TILES; k++) {
+                const int r = dy * GSR_SS_TILES + k - ly0;
+                if (r < 0 || r >= rows) continue;
+                const uint32_t bb = (uint32_t)(sp >> (8 * r)) & 0xffu;
+                const int c0 = lx0 + (int)(bb & 15u), c1 = lx0 + (int)(bb >> 4);
+                const int lo = max(c0, bx) - bx, hi = min(c1, bx + GSR_SS_TILES) - bx;
+                if (hi > lo) m |= (((1u << hi) - 1u) & ~((1u << lo) - 1u)) << (4 * k);
+            }
+            if (m) f(bin0 + dy * SX + dx, m, id, sr.x);
+        }
+}
+
+template <class F>
+__device__ __forceinline__ void ss_for_chunk_entries(const SsBinArgs &a, const SsLds &l, F f) {
     const int i0 = blockIdx.x * a.chunk, i1 = min(a.P, i0 + a.chunk);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int base = i0; base < i1; base += 4 * SS_THREADS) {
@@ -130,13 +156,17 @@ __device__ __forceinline__ void ss_for_chunk_entries(const SsBinArgs &a, uint32_
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t kind = sr[k].y >> 30;
+            const uint32_t kind = sr[k].y >> 29;
             if (!kind) continue;
             const int i = base + k * SS_THREADS + (int)threadIdx.x;
-            // deferred: large rectangles from the front of the list, medium ones from its back (at most `chunk` together)
-            if (kind == 2u) { big[atomicAdd(nbig, 1u)] = (uint32_t)i; continue; }
-            if (kind == 3u) { big[a.chunk - 1 - (int)atomicAdd(nmid, 1u)] = (uint32_t)i; continue; }
-            const int bin0 = (int)(sr[k].y & 0x3fffffffu);
+            if (kind == 2u) { l.big[atomicAdd(l.nbig, 1u)] = (uint32_t)i; continue; }      // at most `chunk` of them
+            if (kind == 3u) {
+                const uint32_t slot = atomicAdd(l.nmid, 1u);
+                if (slot < GSR_SS_MIDCAP) { l.midrec[slot] = sr[k]; l.midid[slot] = (uint32_t)i; }
+                else ss_mid_item(sr[k], (uint32_t)i, a.SX, f);                           // list full: in place
+                continue;
+            }
+            const int bin0 = (int)(sr[k].y & 0x3ffffu);
             // the four masks preprocess assembled: super-tiles (dx, dy) of the 2 x 2 block from bin0 (an empty mask where the
             // block leaves the grid)
             if (sr[k].z & 0xffffu) f(bin0, sr[k].z & 0xffffu, (uint32_t)i, sr[k].x);
@@ -146,29 +176,16 @@ __device__ __forceinline__ void ss_for_chunk_entries(const SsBinArgs &a, uint32_
         }
     }
     __syncthreads();
-    // medium rectangles (row spans packed by preprocess, but more than 2 x 2 super-tiles): one per lane, densely
-    const int nm = (int)*nmid;
-    for (int k = (int)threadIdx.x; k < nm; k += SS_THREADS) {
-        const int i = (int)big[a.chunk - 1 - k];
-        const uint4 rc = a.rect[i];
-        const uint32_t d = a.depth_bits[i];
-        const uint64_t sp = (uint64_t)rc.z | ((uint64_t)rc.w << 32);
-        const SsRect q = ss_rect(rc, a.SX, a.SY);
-        for (int sy = q.sy0; sy < q.sy1; sy++)
-            for (int sx = q.sx0; sx < q.sx1; sx++) {
-                const uint32_t m = ss_mask_small(q, sp, sx, sy);
-                if (m) f(sy * a.SX + sx, m, (uint32_t)i, d);
-            }
-    }
-    const int nb = (int)*nbig;
-    uint32_t *my_spans = spans + w * 64;
+    const int nb = (int)*l.nbig, nm = min((int)*l.nmid, GSR_SS_MIDCAP);
+    uint32_t *my_spans = l.spans + w * 64;
     // one wave per large rectangle; wave w takes items w, w + 16, ...  Their records are fetched 64 at a time, one item per
-    // lane, and broadcast from that lane when the item's turn comes: one memory latency per 64 items instead of one each
+    // lane, and broadcast from that lane when the item's turn comes: one memory latency per 64 items instead of one each --
+    // and the first batch is in flight while the medium rectangles are worked off
     constexpr int NW = SS_THREADS / 64;
-    for (int k0 = w; k0 < nb; k0 += NW * 64) {
+    for (int k0 = w, first = 1; first || k0 < nb; k0 += NW * 64, first = 0) {
         const int kl = k0 + NW * lane;
         const bool have = kl < nb;
-        const int iv = have ? (int)big[kl] : 0;
+        const int iv = have ? (int)l.big[kl] : 0;
         uint4 rcv = make_uint4(0u, 0u, 0u, 0u);
         uint32_t dv = 0u;
         float4 r0v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -178,7 +195,9 @@ __device__ __forceinline__ void ss_for_chunk_entries(const SsBinArgs &a, uint32_
             const float4 *rp = reinterpret_cast<const float4 *>(a.rec) + 3 * (size_t)iv;
             r0v = rp[0]; conCv = rp[1].x; tauv = rp[2].z;
         }
-        const int cnt = min(64, (nb - k0 + NW - 1) / NW);               // wave-uniform
+        if (first)                                                      // medium rectangles: one per lane, densely
+            for (int k = (int)threadIdx.x; k < nm; k += SS_THREADS) ss_mid_item(l.midrec[k], l.midid[k], a.SX, f);
+        const int cnt = k0 < nb ? min(64, (nb - k0 + NW - 1) / NW) : 0;    // wave-uniform
         for (int j = 0; j < cnt; j++) {
 #define SS_BC(x) __builtin_amdgcn_readlane((int)(x), j)
 #define SS_BCF(x) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), j))
@@ -220,16 +239,17 @@ __device__ __forceinline__ void ss_for_chunk_entries(const SsBinArgs &a, uint32_
 
 // ---- 1: exact entry counts: per (workgroup, super-tile) for the scatter pass, per super-tile (global) for the scan ----
 __global__ __launch_bounds__(SS_THREADS) void ss_count_kernel(SsBinArgs a) {
-    extern __shared__ uint32_t sm[];                       // h[S] | big[chunk] | spans[16][64]
+    extern __shared__ __align__(16) uint32_t sm[];         // lists (ss_carve_lds) | h[S]
     __shared__ uint32_t s_sum[2][SS_THREADS / 64];
     __shared__ uint32_t s_nbig, s_nmid;
     const int S = a.SX * a.SY;
-    uint32_t *h = sm, *big = sm + S, *spans = big + a.chunk;
+    const SsLds l = ss_carve_lds(sm, a.chunk, &s_nbig, &s_nmid);
+    uint32_t *h = sm + SS_LDS_LIST_WORDS(a.chunk);
     for (int b = threadIdx.x; b < S; b += SS_THREADS) h[b] = 0u;
     if (threadIdx.x == 0) { s_nbig = 0u; s_nmid = 0u; }
     __syncthreads();
     uint32_t pairs = 0, ents = 0;
-    ss_for_chunk_entries(a, big, &s_nbig, &s_nmid, spans, [&](int bin, uint32_t m, uint32_t, uint32_t) {
+    ss_for_chunk_entries(a, l, [&](int bin, uint32_t m, uint32_t, uint32_t) {
         atomicAdd(&h[bin], 1u); pairs += (uint32_t)__popc(m); ents++;
     });
     pairs = ss_wave_sum(pairs); ents = ss_wave_sum(ents);
@@ -294,11 +314,12 @@ __global__ __launch_bounds__(SS_THREADS) void ss_scan_kernel(int S, uint32_t eca
 // ---- 3: entries to their bins (arbitrary order inside a bin; the sort of step 4 only looks at the keys).  The workgroup
 //      knows its exact count per bin from step 1 (same chunk, same code), reserves one run per touched bin and fills it ----
 __global__ __launch_bounds__(SS_THREADS) void ss_scatter_kernel(SsBinArgs a) {
-    extern __shared__ uint32_t sm[];                       // run base[S] | rank[S] | prs[S] | big[chunk] | spans[16][64]
+    extern __shared__ __align__(16) uint32_t sm[];         // lists (ss_carve_lds) | run base[S] | rank[S] | prs[S]
     __shared__ uint32_t s_nbig, s_nmid;
     const int S = a.SX * a.SY;
     if (a.hdr[DO_OVERFLOW]) return;                        // grid-uniform: the host takes another path for this frame
-    uint32_t *basep = sm, *rank = sm + S, *prs = sm + 2 * S, *big = sm + 3 * S, *spans = big + a.chunk;
+    const SsLds l = ss_carve_lds(sm, a.chunk, &s_nbig, &s_nmid);
+    uint32_t *basep = sm + SS_LDS_LIST_WORDS(a.chunk), *rank = basep + S, *prs = basep + 2 * S;
     const uint32_t *row = a.wg_cnt + (size_t)blockIdx.x * S;
     for (int b = threadIdx.x; b < S; b += SS_THREADS) {
         const uint32_t c = row[b];
@@ -307,7 +328,7 @@ __global__ __launch_bounds__(SS_THREADS) void ss_scatter_kernel(SsBinArgs a) {
     }
     if (threadIdx.x == 0) { s_nbig = 0u; s_nmid = 0u; }
     __syncthreads();
-    ss_for_chunk_entries(a, big, &s_nbig, &s_nmid, spans, [&](int bin, uint32_t m, uint32_t id, uint32_t d) {
+    ss_for_chunk_entries(a, l, [&](int bin, uint32_t m, uint32_t id, uint32_t d) {
         a.entries[basep[bin] + atomicAdd(&rank[bin], 1u)] = make_uint4(d, id, m, 0u);
         atomicAdd(&prs[bin], (uint32_t)__popc(m));
     });
@@ -504,9 +525,9 @@ hipError_t launch_super_sort_count(const GeomView &g, int P, int W, int H, int e
     const SuperSortPlan pl = super_sort_plan(P, W, H);
     const SuperSortView v = super_sort_view(g);
     static std::atomic<uint64_t> attr{0};
-    const size_t lds = ((size_t)pl.S + pl.chunk + 16 * 64) * sizeof(uint32_t);
+    const size_t lds = ((size_t)pl.S + SS_LDS_LIST_WORDS(pl.chunk)) * sizeof(uint32_t);
     if (lds > 48 * 1024) {
-        const hipError_t e = ss_set_lds_attr(reinterpret_cast<const void *>(ss_count_kernel), ((size_t)GSR_SS_MAXS + GSR_SS_MAX_CHUNK + 16 * 64) * sizeof(uint32_t), attr);
+        const hipError_t e = ss_set_lds_attr(reinterpret_cast<const void *>(ss_count_kernel), ((size_t)GSR_SS_MAXS + SS_LDS_LIST_WORDS(GSR_SS_MAX_CHUNK)) * sizeof(uint32_t), attr);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(ss_count_kernel, dim3(pl.nblk), dim3(SS_THREADS), lds, s, ss_bin_args(g, pl, v, P, W, H, exact_cull));
@@ -519,9 +540,9 @@ hipError_t launch_super_sort_scatter(const GeomView &g, int P, int W, int H, int
     const SuperSortPlan pl = super_sort_plan(P, W, H);
     const SuperSortView v = super_sort_view(g);
     static std::atomic<uint64_t> attr{0};
-    const size_t lds = ((size_t)3 * pl.S + pl.chunk + 16 * 64) * sizeof(uint32_t);
+    const size_t lds = ((size_t)3 * pl.S + SS_LDS_LIST_WORDS(pl.chunk)) * sizeof(uint32_t);
     if (lds > 48 * 1024) {
-        const hipError_t e = ss_set_lds_attr(reinterpret_cast<const void *>(ss_scatter_kernel), ((size_t)3 * GSR_SS_MAXS + GSR_SS_MAX_CHUNK + 16 * 64) * sizeof(uint32_t), attr);
+        const hipError_t e = ss_set_lds_attr(reinterpret_cast<const void *>(ss_scatter_kernel), ((size_t)3 * GSR_SS_MAXS + SS_LDS_LIST_WORDS(GSR_SS_MAX_CHUNK)) * sizeof(uint32_t), attr);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(ss_scatter_kernel, dim3(pl.nblk), dim3(SS_THREADS), lds, s, ss_bin_args(g, pl, v, P, W, H, exact_cull));

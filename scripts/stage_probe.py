@@ -19,7 +19,8 @@ rs = GaussianRasterizationSettings(image_height=cam.image_height, image_width=ca
                                    sh_degree=sc.sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
 lib = _lib.load()
 names = (C.c_char_p * _lib.GSR_NUM_STAGES)(); ms = (C.c_float * _lib.GSR_NUM_STAGES)()
-for mode in ("shs", "colors_precomp"):
+for mode, exact in (("shs", 1), ("colors_precomp", 1), ("shs", 0), ("colors_precomp", 0)):
+    _lib.set_option("exact_tile_cull", exact)
     def step():
         means2D = torch.zeros((sc.P, 3), device=dev, requires_grad=True)
         kw = dict(shs=shs) if mode == "shs" else dict(colors_precomp=colors)
@@ -34,5 +35,5 @@ for mode in ("shs", "colors_precomp"):
     for _ in range(10):
         step(); lib.gsr_get_stage_times(names, ms); acc += np.array(list(ms))
     lib.gsr_set_profiling(0)
-    print(json.dumps({"mode": mode, "visible_frac": float((radii > 0).float().mean()),
+    print(json.dumps({"mode": mode, "exact_tile_cull": exact, "visible_frac": float((radii > 0).float().mean()),
                       **{names[i].decode(): round(float(acc[i] / 10), 4) for i in range(_lib.GSR_NUM_STAGES)}}))
