@@ -353,7 +353,7 @@ __global__ __launch_bounds__(SS_THREADS, CAP <= GSR_SS_CAP ? 8 : 4) void ss_sort
     __shared__ uint32_t start[SS_NSUB + 1], cur[SS_NSUB];
     __shared__ uint32_t wred[3][SS_THREADS / 64];
     __shared__ uint32_t s_kmin, s_kmax, s_before;
-    __shared__ uint32_t tile_cnt[16], tile_start[17];
+    __shared__ uint32_t tile_start[16];
     if (a.hdr[DO_OVERFLOW]) return;                                // grid-uniform
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t e0 = a.bin_start[s];
@@ -471,34 +471,79 @@ __global__ __launch_bounds__(SS_THREADS, CAP <= GSR_SS_CAP ? 8 : 4) void ss_sort
             if (tid + q * SS_THREADS < n) { sid[rk[q]] = id[q]; smask[rk[q]] = (uint16_t)mm[q]; }
     }
     __syncthreads();
-    // ---- expansion: wave t owns tile t of the super-tile (16 waves, 16 tiles) ----
-    const uint32_t bit = 1u << w;
-    uint32_t total = 0;
-    for (int j0 = 0; j0 < n; j0 += 64) {
-        const int j = j0 + lane;
-        const bool has = j < n && (smask[j] & bit);
-        total += (uint32_t)__popcll(__ballot(has));
+    // ---- expansion: the sorted entries -> the 16 per-tile lists.  Every thread takes ITEMS consecutive sorted entries and needs,
+    // for each of the 16 tiles, how many earlier entries carry that tile's bit: a 16-component prefix sum.  The components are
+    // packed two to a word (16 bits each, n <= 14 336), so that one workgroup scan of 8 words does all tiles at once; a wave
+    // sweeping all n entries for one tile (the first version) spent 26 of this kernel's 42 us on ballots.
+    uint32_t m[ITEMS], idv[ITEMS];
+    const int jb = tid * ITEMS;
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+        const int j = jb + q;
+        m[q] = j < n ? (uint32_t)smask[j] : 0u;
+        idv[q] = j < n ? sid[j] : 0u;
     }
-    if (lane == 0) tile_cnt[w] = total;
+    // this thread's entries per tile, two tiles to a word (word k: tile 2k | tile 2k + 1 << 16)
+    auto local_counts = [&](uint32_t c[8]) {
+        // bit k of a byte -> nibble k of a word; the per-thread counts (<= ITEMS <= 14 < 16) add up nibble-wise
+        auto spread8 = [](uint32_t x) {
+            x = (x | (x << 12)) & 0x000f000fu; x = (x | (x << 6)) & 0x03030303u; x = (x | (x << 3)) & 0x11111111u;
+            return x;
+        };
+        uint32_t nlo = 0u, nhi = 0u;
+#pragma unroll
+        for (int q = 0; q < ITEMS; q++) { nlo += spread8(m[q] & 0xffu); nhi += spread8(m[q] >> 8); }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t src = k < 4 ? nlo : nhi;
+            const int sh = 8 * (k & 3);
+            c[k] = ((src >> sh) & 0xfu) | (((src >> (sh + 4)) & 0xfu) << 16);
+        }
+    };
+    uint32_t c[8];
+    local_counts(c);
+    __shared__ uint32_t wtab[SS_THREADS / 64][8];
+    uint32_t ex[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t incl = ss_wave_incl_scan(c[k], lane);
+        ex[k] = incl - c[k];
+        if (lane == 63) wtab[w][k] = incl;
+    }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t run = s_before;
-        for (int t = 0; t < 16; t++) { tile_start[t] = run; run += tile_cnt[t]; }
-        tile_start[16] = run;
+    for (int k = 0; k < w; k++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) ex[u] += wtab[k][u];
+    }
+    if (tid < 16) {                                                    // tile totals, their exclusive scan, the ranges
+        uint32_t tot = 0u;
+        for (int k = 0; k < SS_THREADS / 64; k++) tot += (wtab[k][tid >> 1] >> (16 * (tid & 1))) & 0xffffu;
+        uint32_t incl = tot;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if (tid >= d) incl += t;
+        }
+        const uint32_t st = s_before + incl - tot;
+        tile_start[tid] = st;
+
+        const int tx = (s % a.SX) * GSR_SS_TILES + (tid & 3), ty = (s / a.SX) * GSR_SS_TILES + (tid >> 2);
+        if (tx < a.gridx && ty < a.gridy) a.ranges[ty * a.gridx + tx] = make_uint2(st, st + tot);
     }
     __syncthreads();
-    const uint32_t my_start = tile_start[w];
-    {
-        const int tx = (s % a.SX) * GSR_SS_TILES + (w & 3), ty = (s / a.SX) * GSR_SS_TILES + (w >> 2);
-        if (lane == 0 && tx < a.gridx && ty < a.gridy) a.ranges[ty * a.gridx + tx] = make_uint2(my_start, my_start + total);
-    }
-    uint32_t run = my_start;
-    for (int j0 = 0; j0 < n; j0 += 64) {
-        const int j = j0 + lane;
-        const bool has = j < n && (smask[j] & bit);
-        const unsigned long long bal = __ballot(has);
-        if (has) a.point_list[run + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = sid[j];
-        run += (uint32_t)__popcll(bal);
+    // 16 * ITEMS predicated 4-byte stores per thread; consecutive lanes hold consecutive entries, so the lanes that do store for
+    // a tile hit neighbouring addresses.  (Staging the super-tile's lists in LDS and copying them out densely was measured: slower.)
+    uint32_t pos[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) pos[t] = tile_start[t] + ((ex[t >> 1] >> (16 * (t & 1))) & 0xffffu);
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const uint32_t bitv = (m[q] >> t) & 1u;
+            if (bitv) a.point_list[pos[t]] = idv[q];
+            pos[t] += bitv;
+        }
     }
 }
 
