@@ -144,7 +144,10 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
             const StagedConic sc = stage_conic(r0.z, r0.w, r1.x);       // as the forward pass staged it
             my[lane * 3 + 0] = make_float4(r0.x, r0.y, sc.a, sc.b);
             my[lane * 3 + 1] = make_float4(sc.c, r1.y, r1.z, r1.w);
-            my[lane * 3 + 2] = make_float4(r2.x, 0.f, __uint_as_float(bits), __uint_as_float(g));
+            // accumulator row: the Gaussian's own, or -- for a splat with replica rows (gsr_internal.h) -- replica (tile mod K)
+            const uint32_t hot = __float_as_uint(r2.w);
+            const uint32_t row = hot ? (uint32_t)a.P + (hot >> 4) + ((uint32_t)tile & ((1u << (hot & 15u)) - 1u)) : g;
+            my[lane * 3 + 2] = make_float4(r2.x, 0.f, __uint_as_float(bits), __uint_as_float(row));
         }
         uint64_t todo = __ballot(live);
         if (COUNT) { c_staged += cnt; c_visits += __builtin_popcountll(todo); }
@@ -225,8 +228,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
                 if (DET) {
                     a.det[((size_t)(range.x + pos) * UNITS_PER_TILE + sub) * GSR_ACC_FLOATS + slot] = sel;
                 } else {
-                    const uint32_t g = __float_as_uint(r2.w);
-                    atomicAdd(a.acc + GSR_ACC_FLOATS * (size_t)g + slot, sel);
+                    const uint32_t row = __float_as_uint(r2.w);
+                    atomicAdd(a.acc + GSR_ACC_FLOATS * (size_t)row + slot, sel);
                 }
             }
         };

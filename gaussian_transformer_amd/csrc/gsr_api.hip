@@ -100,6 +100,7 @@ GeomView carve_geom(void *base, int P, size_t scan_tb, size_t dsort_tb) {
     g.depth_sorted = (uint32_t *)take(n * sizeof(uint32_t));
     g.orect = (uint4 *)take(n * sizeof(uint4));
     g.ss_rec = (uint4 *)take(n * sizeof(uint4));
+    g.hot = (uint32_t *)take(n * sizeof(uint32_t));
     g.ss_entries = (uint4 *)take((size_t)GSR_SS_ENT_PER_G * n * sizeof(uint4));
     // the bin count is an image property the workspace size cannot depend on (gsr_workspace_sizes is asked per (P, W, H) but
     // carve_geom only sees P): room for GSR_SS_WGCNT_WORDS words; supertile_sort.hip is skipped when nblk * S exceeds it
@@ -340,13 +341,13 @@ int32_t gsr_workspace_sizes(int32_t P, int32_t W, int32_t H, size_t *geom_bytes,
     HIP_TRY(depth_sort_temp_bytes(P, &dtb), "depth sort temp query");
     if (geom_bytes) *geom_bytes = carve_geom(nullptr, P, stb, dtb).total_bytes;
     if (img_bytes) *img_bytes = carve_image(nullptr, W, H).total_bytes;
-    if (bwd_bytes) *bwd_bytes = align_up((size_t)(P > 0 ? P : 1) * GSR_ACC_FLOATS * sizeof(float));
+    if (bwd_bytes) *bwd_bytes = align_up(acc_rows(P) * GSR_ACC_FLOATS * sizeof(float));
     return GSR_OK;
 }
 
 int32_t gsr_backward_workspace_bytes(int32_t P, int64_t R, size_t *bytes) {
     if (P < 0 || R < 0 || !bytes) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward_workspace_bytes: bad argument");
-    const size_t acc_bytes = align_up((size_t)(P > 0 ? P : 1) * GSR_ACC_FLOATS * sizeof(float));
+    const size_t acc_bytes = align_up(acc_rows(P) * GSR_ACC_FLOATS * sizeof(float));
     const size_t det_bytes = g_deterministic_bwd.load() ? (size_t)R * (size_t)(4 / g_bwd_npx.load()) * GSR_ACC_FLOATS * sizeof(float) : 0;
     *bytes = acc_bytes + align_up(det_bytes);
     return GSR_OK;
@@ -605,7 +606,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     BinningView b = carve_binning(const_cast<void *>(binning_ws), R, 0);
     if (R > 0 && binning_bytes < align_up((size_t)R * sizeof(uint32_t)) + align_up(4 * (size_t)R))
         return fail(GSR_ERR_WORKSPACE, "binning workspace too small for R=%lld", (long long)R);
-    const size_t acc_bytes = (size_t)P * GSR_ACC_FLOATS * sizeof(float);
+    const size_t acc_bytes = acc_rows(P) * GSR_ACC_FLOATS * sizeof(float);
     if (bwd_bytes < acc_bytes) return fail(GSR_ERR_WORKSPACE, "backward workspace %zu < %zu", bwd_bytes, acc_bytes);
     const bool det = g_deterministic_bwd.load() != 0 && R > 0;
     const int bwd_npx = g_bwd_npx.load();
@@ -637,7 +638,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     pa.P = P; pa.D = D; pa.M = M; pa.W = W; pa.H = H; pa.means3D = means3D; pa.shs = shs; pa.colors_precomp = colors_precomp;
     pa.scales = scales; pa.rotations = rotations; pa.cov3D_precomp = cov3D_precomp; pa.viewmatrix = viewmatrix;
     pa.projmatrix = projmatrix; pa.campos = campos; pa.scale_modifier = scale_modifier; pa.tanfovx = tanfovx;
-    pa.tanfovy = tanfovy; pa.radii = radii; pa.clamped = g.clamped; pa.opac = g.opac; pa.acc = (const float *)bwd_ws;
+    pa.tanfovy = tanfovy; pa.radii = radii; pa.clamped = g.clamped; pa.opac = g.opac; pa.acc = (const float *)bwd_ws; pa.hot = g.hot;
     pa.dL_dmeans2D = dL_dmeans2D; pa.dL_dopacity = dL_dopacity; pa.dL_dcolors = dL_dcolors; pa.dL_dmeans3D = dL_dmeans3D;
     pa.dL_dcov3D = dL_dcov3D; pa.dL_dsh = dL_dsh; pa.dL_dscales = dL_dscales; pa.dL_drots = dL_drots;
     HIP_TRY(launch_pergauss_bwd(pa, s), "per-Gaussian backward launch");

@@ -13,12 +13,20 @@ static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a
 static inline int ceil_log2_u32(uint32_t x) { int b = 0; while ((1u << b) < x && b < 31) b++; return b; }
 
 // Per-Gaussian record gathered by the compositing kernels: 12 floats = 3 x float4.
-//   [0] px  [1] py  [2] conic.xx  [3] conic.xy | [4] conic.yy [5] opacity [6] r [7] g | [8] b [9] depth [10] cull tau [11] -
+//   [0] px  [1] py  [2] conic.xx  [3] conic.xy | [4] conic.yy [5] opacity [6] r [7] g | [8] b [9] depth [10] cull tau [11] replica code of the accumulator rows (bits; 0 = none)
 #define GSR_REC_FLOATS 12
 // Gradient accumulator of the reverse compositing pass: one 64-byte row per Gaussian so that the
 // nine atomics of one (tile, Gaussian) pair fall into a single memory-side atomic request.
 //   [0..2] dL/drgb  [3..4] sum s*d  [5..7] sum s*d d^T  [8] sum s,  s = opacity * G * dL/dalpha, d = centre - pixel
 #define GSR_ACC_FLOATS 16
+// A splat that covers hundreds of tiles receives one atomic per (wave, tile): they all meet in one 64-byte row and serialise
+// in L2 (tiramisu ring cameras: 0.12 ms of a 0.42 ms reverse pass).  Such a splat gets 4..16 replica rows behind the P regular
+// ones, the wave of tile t adds into replica t mod K, pergauss_bwd.hip sums them.  The code of a Gaussian: 0 = no replicas,
+// else (first replica row - P) << 4 | log2 K; kept in hot[] (for pergauss_bwd) and in the record's spare float [11] (for the
+// compositing kernel, which has the record in registers anyway).  Rows are handed out by supertile_sort.hip's counting kernel.
+#define GSR_HOT_MIN_TILES 256   // fewer than 1 in 2000 Gaussians at config 3 (pergauss_bwd's fold loop diverges its wave)
+static inline size_t acc_extra_rows(int P) { return (size_t)(P > 0 ? P : 1) / 32 + 1024; }
+static inline size_t acc_rows(int P) { return (size_t)(P > 0 ? P : 1) + acc_extra_rows(P); }
 
 // ---- depth_order.hip: bucketed depth order (replaces the rocPRIM depth sort + ordered scan) ----
 #define GSR_DO_CAP 8192      // largest level-1 bucket one workgroup orders in LDS (64 KB of 64-bit keys)
@@ -48,7 +56,7 @@ struct DepthOrderView {
 #define GSR_SS_MIDCAP 1024     // medium rectangles one counting / scatter workgroup keeps as records in LDS (more: handled in place)
 #define GSR_SS_ENT_PER_G 4     // capacity of the entry array in the geometry workspace, per Gaussian
 #define GSR_SS_WGCNT_WORDS (4 << 20)   // per-(counting workgroup, super-tile) counts: 16 MB (1024 workgroups x 4096 super-tiles)
-enum { SS_HDR_MAXBIN = 7, SS_HDR_N = 8, SS_HDR_E = 9 };   // words of the header next to DO_OVERFLOW (zeroed by preprocess)
+enum { SS_HDR_MAXBIN = 7, SS_HDR_N = 8, SS_HDR_E = 9, SS_HDR_HOT = 10 };   // words of the header next to DO_OVERFLOW (zeroed by preprocess)
 struct SuperSortPlan { int SX, SY, S, chunk, nblk; int64_t ecap; };
 SuperSortPlan super_sort_plan(int P, int W, int H);
 struct SuperSortView {
@@ -75,6 +83,7 @@ struct GeomView {          // per-Gaussian state, P entries each
                            //     kind 0: emits nothing; 1: zw = the 16-bit tile masks of the 2 x 2 super-tiles from that bin;
                            //     3: <= 8 rows x <= 15 columns: zw = row spans, byte k = (c0 - x0) | (c1 - x0) << 4 of row y0 + k;
                            //     2: larger rectangle (spans re-evaluated from rect / rec)
+    uint32_t *hot;         // [P] replica code of the gradient accumulator rows (GSR_HOT_MIN_TILES above); 0 from preprocess
     uint4 *ss_entries;     // [GSR_SS_ENT_PER_G * P] supertile_sort.hip: (depth bits, id, 16-bit tile mask, -) grouped by super-tile
     uint32_t *ss_wg_cnt;   // [counting workgroups][S] entries per (workgroup of 4096 Gaussians, super-tile)
     uint32_t *tl_mat1;     // [GSR_TL_MAX_S][ceil(P / 512)] tile_lists.hip level-1 count matrix (filled before N is known)
@@ -221,7 +230,7 @@ struct CompositeBwdArgs {
     const float *final_T;
     const uint32_t *n_contrib;
     const float *dL_dpix;
-    float *acc;   // [P][16], zeroed
+    float *acc;   // [P + acc_extra_rows(P)][16], zeroed
     // deterministic mode only (det != NULL): one 16-float slot per (list entry, wave of the tile), zeroed; the geometry
     // det_reduce_kernel needs to find a Gaussian's entries again
     float *det;
@@ -246,6 +255,7 @@ struct PergaussBwdArgs {
     const int *radii;
     const uint8_t *clamped;
     const float *acc;
+    const uint32_t *hot;     // [P] replica codes (GeomView::hot)
     float *dL_dmeans2D, *dL_dopacity, *dL_dcolors, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drots;
 };
 hipError_t launch_pergauss_bwd(const PergaussBwdArgs &a, hipStream_t s);

@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
     const size_t si = (size_t)i;
     constexpr int K = (D + 1) * (D + 1);
     const bool visible = a.radii[si] > 0;
+    const uint32_t hot = a.hot[si];      // requested together with radii: the branch on it further down then costs no second round trip
     // dL/dshs rows of a whole wave (64 Gaussians x 192 B at M = 16) are contiguous in memory: the lanes put their rows into a
     // wave-private LDS tile and the wave copies the tile out with 16-byte stores at consecutive addresses (12 x 1 KiB), instead
     // of 48 dword stores per lane at a 192-byte stride that leave every 128-byte line half written 48 times over.
@@ -40,8 +41,18 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
 
     if (visible) {
         const float4 *acc4 = reinterpret_cast<const float4 *>(a.acc) + 4 * si;
-        const float4 A0 = acc4[0], A1 = acc4[1];
-        const float A8 = a.acc[GSR_ACC_FLOATS * si + 8];
+        float4 A0 = acc4[0], A1 = acc4[1];
+        float A8 = a.acc[GSR_ACC_FLOATS * si + 8];
+        if (hot) {                                            // a splat over hundreds of tiles: its waves added into replica rows
+            const size_t first = (size_t)a.P + (hot >> 4);
+            for (uint32_t k = 0; k < (1u << (hot & 15u)); k++) {
+                const float4 *r4 = reinterpret_cast<const float4 *>(a.acc) + 4 * (first + k);
+                const float4 B0 = r4[0], B1 = r4[1];
+                A0.x += B0.x; A0.y += B0.y; A0.z += B0.z; A0.w += B0.w;
+                A1.x += B1.x; A1.y += B1.y; A1.z += B1.z; A1.w += B1.w;
+                A8 += a.acc[GSR_ACC_FLOATS * (first + k) + 8];
+            }
+        }
         dcol[0] = A0.x; dcol[1] = A0.y; dcol[2] = A0.z;
 
         const float p[3] = {a.means3D[3 * si], a.means3D[3 * si + 1], a.means3D[3 * si + 2]};

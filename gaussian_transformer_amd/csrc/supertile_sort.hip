@@ -82,7 +82,10 @@ struct SsBinArgs {
     const uint4 *ss_rec;             // per Gaussian: what preprocess prepared for this path (GeomView::ss_rec)
     const uint4 *rect;               // large rectangles only
     const uint32_t *depth_bits;
-    const float *rec;
+    float *rec;
+    const uint32_t *tiles;           // pairs per Gaussian (large rectangles: who gets replica accumulator rows)
+    uint32_t *hot;                   // [P] replica codes, written by the counting kernel for the largest splats
+    uint32_t hot_cap;                // replica rows available (acc_extra_rows)
     uint32_t *hdr;
     uint32_t *bin_cnt;               // [S] global entry counts (count kernel: atomics)
     uint32_t *wg_cnt;                // [nblk][S] entries of every counting workgroup per bin (count kernel writes, scatter reads)
@@ -142,7 +145,8 @@ __device__ __forceinline__ void ss_mid_item(const uint4 sr, uint32_t id, int SX,
         }
 }
 
-template <class F>
+// HOT (the counting kernel only): the lane that fetches a large rectangle also decides whether the splat gets replica rows
+template <bool HOT, class F>
 __device__ __forceinline__ void ss_for_chunk_entries(const SsBinArgs &a, const SsLds &l, F f) {
     const int i0 = blockIdx.x * a.chunk, i1 = min(a.P, i0 + a.chunk);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -194,6 +198,18 @@ __device__ __forceinline__ void ss_for_chunk_entries(const SsBinArgs &a, const S
             rcv = a.rect[iv]; dv = a.depth_bits[iv];
             const float4 *rp = reinterpret_cast<const float4 *>(a.rec) + 3 * (size_t)iv;
             r0v = rp[0]; conCv = rp[1].x; tauv = rp[2].z;
+            if (HOT) {
+                const uint32_t t = a.tiles[iv];
+                if (t >= GSR_HOT_MIN_TILES) {                            // K = 4 .. 16 replicas, 64 tiles each or more
+                    const uint32_t lg = min(4u, 31u - (uint32_t)__clz((int)(t / 64u)));
+                    const uint32_t base = atomicAdd(&a.hdr[SS_HDR_HOT], 1u << lg);
+                    if (base + (1u << lg) <= a.hot_cap) {
+                        const uint32_t code = (base << 4) | lg;
+                        a.hot[iv] = code;
+                        reinterpret_cast<uint32_t *>(a.rec)[(size_t)GSR_REC_FLOATS * iv + 11] = code;
+                    }
+                }
+            }
         }
         if (first)                                                      // medium rectangles: one per lane, densely
             for (int k = (int)threadIdx.x; k < nm; k += SS_THREADS) ss_mid_item(l.midrec[k], l.midid[k], a.SX, f);
@@ -249,7 +265,7 @@ __global__ __launch_bounds__(SS_THREADS) void ss_count_kernel(SsBinArgs a) {
     if (threadIdx.x == 0) { s_nbig = 0u; s_nmid = 0u; }
     __syncthreads();
     uint32_t pairs = 0, ents = 0;
-    ss_for_chunk_entries(a, l, [&](int bin, uint32_t m, uint32_t, uint32_t) {
+    ss_for_chunk_entries<true>(a, l, [&](int bin, uint32_t m, uint32_t, uint32_t) {
         atomicAdd(&h[bin], 1u); pairs += (uint32_t)__popc(m); ents++;
     });
     pairs = ss_wave_sum(pairs); ents = ss_wave_sum(ents);
@@ -328,7 +344,7 @@ __global__ __launch_bounds__(SS_THREADS) void ss_scatter_kernel(SsBinArgs a) {
     }
     if (threadIdx.x == 0) { s_nbig = 0u; s_nmid = 0u; }
     __syncthreads();
-    ss_for_chunk_entries(a, l, [&](int bin, uint32_t m, uint32_t id, uint32_t d) {
+    ss_for_chunk_entries<false>(a, l, [&](int bin, uint32_t m, uint32_t id, uint32_t d) {
         a.entries[basep[bin] + atomicAdd(&rank[bin], 1u)] = make_uint4(d, id, m, 0u);
         atomicAdd(&prs[bin], (uint32_t)__popc(m));
     });
@@ -561,6 +577,7 @@ static SsBinArgs ss_bin_args(const GeomView &g, const SuperSortPlan &pl, const S
     SsBinArgs a;
     a.P = P; a.chunk = pl.chunk; a.SX = pl.SX; a.SY = pl.SY; a.W = W; a.H = H; a.exact_cull = exact_cull;
     a.ss_rec = g.ss_rec; a.rect = g.rect; a.depth_bits = reinterpret_cast<const uint32_t *>(g.depth); a.rec = g.rec;
+    a.tiles = g.tiles; a.hot = g.hot; a.hot_cap = (uint32_t)acc_extra_rows(P);
     a.hdr = v.hdr; a.bin_cnt = v.bin_cnt; a.wg_cnt = g.ss_wg_cnt; a.bin_start = v.bin_start; a.bin_cur = v.bin_cur; a.bin_pairs = v.bin_pairs;
     a.entries = g.ss_entries;
     return a;
