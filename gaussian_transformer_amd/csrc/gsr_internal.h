@@ -22,7 +22,7 @@ static inline int ceil_log2_u32(uint32_t x) { int b = 0; while ((1u << b) < x &&
 // A splat that covers hundreds of tiles receives one atomic per (wave, tile): they all meet in one 64-byte row and serialise
 // in L2 (tiramisu ring cameras: 0.12 ms of a 0.42 ms reverse pass).  Such a splat gets 4..16 replica rows behind the P regular
 // ones, the wave of tile t adds into replica t mod K, pergauss_bwd.hip sums them.  The code of a Gaussian: 0 = no replicas,
-// else (first replica row - P) << 4 | log2 K; kept in hot[] (for pergauss_bwd) and in the record's spare float [11] (for the
+// else (first replica row - P) << 4 | log2 K; kept in hot[] (for pergauss_bwd, flagged by bit 7 of clamped[]) and in the record's spare float [11] (for the
 // compositing kernel, which has the record in registers anyway).  Rows are handed out by supertile_sort.hip's counting kernel.
 #define GSR_HOT_MIN_TILES 256   // fewer than 1 in 2000 Gaussians at config 3 (pergauss_bwd's fold loop diverges its wave)
 static inline size_t acc_extra_rows(int P) { return (size_t)(P > 0 ? P : 1) / 32 + 1024; }
@@ -74,7 +74,7 @@ struct GeomView {          // per-Gaussian state, P entries each
                            //     byte k = (c0 - x0) | (c1 - x0) << 4 of row y0 + k; all ones = not representable
     uint32_t *tiles;       // [P] (Gaussian,tile) pairs emitted (== rect area when exact culling is off)
     uint32_t *offsets;     // [P] inclusive scan of tiles[perm[.]] (depth order)
-    uint8_t *clamped;      // [P] bit ch set iff SH colour channel ch was clamped at 0
+    uint8_t *clamped;      // [P] bit ch (0-2) set iff SH colour channel ch was clamped at 0; bit 7: hot[] holds a replica code
     uint32_t *perm;        // [P] Gaussian ids in (depth, id) order
     uint32_t *depth_sorted;  // [P] sorted depth bits (by-product of the depth sort)
     uint4 *orect;          // [P] rect[perm[.]]: the same records in depth order (empty rectangle for a Gaussian that emits nothing)
@@ -83,7 +83,7 @@ struct GeomView {          // per-Gaussian state, P entries each
                            //     kind 0: emits nothing; 1: zw = the 16-bit tile masks of the 2 x 2 super-tiles from that bin;
                            //     3: <= 8 rows x <= 15 columns: zw = row spans, byte k = (c0 - x0) | (c1 - x0) << 4 of row y0 + k;
                            //     2: larger rectangle (spans re-evaluated from rect / rec)
-    uint32_t *hot;         // [P] replica code of the gradient accumulator rows (GSR_HOT_MIN_TILES above); 0 from preprocess
+    uint32_t *hot;         // [P] replica code of the gradient accumulator rows (GSR_HOT_MIN_TILES above); valid where clamped has bit 7
     uint4 *ss_entries;     // [GSR_SS_ENT_PER_G * P] supertile_sort.hip: (depth bits, id, 16-bit tile mask, -) grouped by super-tile
     uint32_t *ss_wg_cnt;   // [counting workgroups][S] entries per (workgroup of 4096 Gaussians, super-tile)
     uint32_t *tl_mat1;     // [GSR_TL_MAX_S][ceil(P / 512)] tile_lists.hip level-1 count matrix (filled before N is known)

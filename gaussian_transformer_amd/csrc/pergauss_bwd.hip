@@ -22,8 +22,12 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
     if (i >= a.P) return;
     const size_t si = (size_t)i;
     constexpr int K = (D + 1) * (D + 1);
-    const bool visible = a.radii[si] > 0;
-    const uint32_t hot = a.hot[si];      // requested together with radii: the branch on it further down then costs no second round trip
+    // radii and the flag byte are requested together and awaited together (the asm ties them: left alone, the compiler sinks the
+    // byte load below the branch on radii, and the branch on its bit 7 then costs a second memory round trip)
+    int rad = a.radii[si];
+    uint32_t cl = a.clamped[si];         // bits 0-2: SH clamp mask; bit 7: the splat has replica accumulator rows
+    asm volatile("" : "+v"(rad), "+v"(cl));
+    const bool visible = rad > 0;
     // dL/dshs rows of a whole wave (64 Gaussians x 192 B at M = 16) are contiguous in memory: the lanes put their rows into a
     // wave-private LDS tile and the wave copies the tile out with 16-byte stores at consecutive addresses (12 x 1 KiB), instead
     // of 48 dword stores per lane at a 192-byte stride that leave every 128-byte line half written 48 times over.
@@ -43,7 +47,8 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
         const float4 *acc4 = reinterpret_cast<const float4 *>(a.acc) + 4 * si;
         float4 A0 = acc4[0], A1 = acc4[1];
         float A8 = a.acc[GSR_ACC_FLOATS * si + 8];
-        if (hot) {                                            // a splat over hundreds of tiles: its waves added into replica rows
+        if (cl & 0x80u) {                                     // a splat over hundreds of tiles: its waves added into replica rows
+            const uint32_t hot = a.hot[si];
             const size_t first = (size_t)a.P + (hot >> 4);
             for (uint32_t k = 0; k < (1u << (hot & 15u)); k++) {
                 const float4 *r4 = reinterpret_cast<const float4 *>(a.acc) + 4 * (first + k);
@@ -141,7 +146,6 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
             float c[3 * K + 3];
             if (SPLIT) load_sh_row_split<K>(a.shs, a.shs_rest, si, a.M, c);
             else load_sh_row<K>(a.shs, si, a.M, c);
-            const uint8_t cl = a.clamped[si];
             float ddir[3] = {0.f, 0.f, 0.f};
             float *out = (SPLIT) ? nullptr : a.dL_dsh + si * (size_t)a.M * 3;
             float gch[3];

@@ -163,7 +163,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
         a.g.rect[si] = rect_out;
         a.g.ss_rec[si] = make_uint4(__float_as_uint(depth_out), ss_y, (uint32_t)ss_w, (uint32_t)(ss_w >> 32));
         a.g.tiles[si] = tiles_out;
-        a.g.hot[si] = 0u;                    // no replica rows (supertile_sort.hip hands them out to the largest splats)
         a.g.clamped[si] = clamp_out;
         a.radii[si] = radius_out;
     }

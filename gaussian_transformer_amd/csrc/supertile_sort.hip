@@ -84,7 +84,8 @@ struct SsBinArgs {
     const uint32_t *depth_bits;
     float *rec;
     const uint32_t *tiles;           // pairs per Gaussian (large rectangles: who gets replica accumulator rows)
-    uint32_t *hot;                   // [P] replica codes, written by the counting kernel for the largest splats
+    uint32_t *hot;                   // [P] replica codes, written by the counting kernel for the largest splats (only theirs)
+    uint8_t *clamped;                // [P] bit 7 := "has a replica code"
     uint32_t hot_cap;                // replica rows available (acc_extra_rows)
     uint32_t *hdr;
     uint32_t *bin_cnt;               // [S] global entry counts (count kernel: atomics)
@@ -206,6 +207,7 @@ __device__ __forceinline__ void ss_for_chunk_entries(const SsBinArgs &a, const S
                     if (base + (1u << lg) <= a.hot_cap) {
                         const uint32_t code = (base << 4) | lg;
                         a.hot[iv] = code;
+                        a.clamped[iv] |= 0x80u;                          // tells pergauss_bwd.hip to look at hot[] (single writer)
                         reinterpret_cast<uint32_t *>(a.rec)[(size_t)GSR_REC_FLOATS * iv + 11] = code;
                     }
                 }
@@ -577,7 +579,7 @@ static SsBinArgs ss_bin_args(const GeomView &g, const SuperSortPlan &pl, const S
     SsBinArgs a;
     a.P = P; a.chunk = pl.chunk; a.SX = pl.SX; a.SY = pl.SY; a.W = W; a.H = H; a.exact_cull = exact_cull;
     a.ss_rec = g.ss_rec; a.rect = g.rect; a.depth_bits = reinterpret_cast<const uint32_t *>(g.depth); a.rec = g.rec;
-    a.tiles = g.tiles; a.hot = g.hot; a.hot_cap = (uint32_t)acc_extra_rows(P);
+    a.tiles = g.tiles; a.hot = g.hot; a.clamped = g.clamped; a.hot_cap = (uint32_t)acc_extra_rows(P);
     a.hdr = v.hdr; a.bin_cnt = v.bin_cnt; a.wg_cnt = g.ss_wg_cnt; a.bin_start = v.bin_start; a.bin_cur = v.bin_cur; a.bin_pairs = v.bin_pairs;
     a.entries = g.ss_entries;
     return a;
