@@ -25,9 +25,10 @@ extern int g_composite_lds_pad;
 
 #define LOG2E 1.4426950408889634f
 #define RED_STRIDE 68
-// LDS per wave: 64 staged records x 3 float4 + the reduction scratch, 9 rows of RED_STRIDE floats (153 float4): 5 520 B, so that
-// 29 waves fit a CU's 160 KB (the kernel is latency-sensitive: 22 waves/CU with a 4 KB scratch cost 9 % at config 3)
-#define BWD_LDS_F4 (64 * 3 + (9 * RED_STRIDE + 3) / 4)
+// LDS per wave: 64 staged records of 40 bytes, kept as three arrays (float4 | float4 | float2) so that every read stays aligned,
+// + the reduction scratch, 9 rows of RED_STRIDE floats (153 float4): 5 008 B -- 32 waves fit a CU's 160 KB, 8 per SIMD (the
+// kernel needs 53 VGPRs and is latency-sensitive: 48-byte records, 29 waves/CU, cost 4 %; 22 waves/CU cost another 9 %)
+#define BWD_LDS_F4 (64 * 2 + 32 + (9 * RED_STRIDE + 3) / 4)
 
 __device__ __forceinline__ int xcd_band_unit(int b, int nblocks_padded) {
     const int chunk = nblocks_padded >> 3;
@@ -74,7 +75,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
     if (tile >= T) return;                            // wave-uniform
     const int tx = tile % a.gridx, ty = tile / a.gridx;
     float4 *my = stage_dyn + wave * BWD_LDS_F4;
-    float *red = reinterpret_cast<float *>(my + 64 * 3);   // [value 0..8][lane 0..63]
+    float2 *myc = reinterpret_cast<float2 *>(my + 128);     // third array of the staged records
+    float *red = reinterpret_cast<float *>(my + 128 + 32);  // [value 0..8][lane 0..63]
     const float4 *rec4 = reinterpret_cast<const float4 *>(a.rec);
     const uint2 range = a.ranges[tile];
     const size_t HW = (size_t)a.W * a.H;
@@ -142,12 +144,12 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
             }
             live = bits != 0u;
             const StagedConic sc = stage_conic(r0.z, r0.w, r1.x);       // as the forward pass staged it
-            my[lane * 3 + 0] = make_float4(r0.x, r0.y, sc.a, sc.b);
-            my[lane * 3 + 1] = make_float4(sc.c, r1.y, r1.z, r1.w);
+            my[lane] = make_float4(r0.x, r0.y, sc.a, sc.b);
+            my[64 + lane] = make_float4(sc.c, r1.y, r1.z, r1.w);
             // accumulator row: the Gaussian's own, or -- for a splat with replica rows (gsr_internal.h) -- replica (tile mod K)
             const uint32_t hot = __float_as_uint(r2.w);
             const uint32_t row = hot ? (uint32_t)a.P + (hot >> 4) + ((uint32_t)tile & ((1u << (hot & 15u)) - 1u)) : g;
-            my[lane * 3 + 2] = make_float4(r2.x, 0.f, __uint_as_float(bits), __uint_as_float(row));
+            myc[lane] = make_float2(r2.x, __uint_as_float(bits | (row << 4)));      // row < 2^28 (checked by gsr_backward)
         }
         uint64_t todo = __ballot(live);
         if (COUNT) { c_staged += cnt; c_visits += __builtin_popcountll(todo); }
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
             __builtin_amdgcn_wave_barrier();
             float sel = 0.f;
             if (red_lane) {
-                const float4 p0 = red_rd[0], p1 = red_rd[1], p2 = red_rd[2], p3 = red_rd[3];
+                const float4 p0 = red_rd[0], p1 = red_rd[1], p2 = red_rd[2], p3 = red_rd[3];       // (v_pk_add_f32 pairs here: 2 % slower)
                 sel = ((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w)) +
                       (((p2.x + p2.y) + (p2.z + p2.w)) + ((p3.x + p3.y) + (p3.z + p3.w)));
             }
@@ -236,8 +238,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
         while (todo) {
             const int j = 63 - __builtin_clzll(todo);
             todo &= ~(1ull << j);
-            const float4 *mj = my + (uint32_t)j * 3u;
-            visit(mj[0], mj[1], mj[2], j);
+            const float2 cj = myc[j];
+            visit(my[j], my[64 + j], make_float4(cj.x, 0.f, __uint_as_float(__float_as_uint(cj.y) & 15u), __uint_as_float(__float_as_uint(cj.y) >> 4)), j);
         }
     }
     if (COUNT && lane == 0 && a.counters) {

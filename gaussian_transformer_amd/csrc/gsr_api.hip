@@ -606,6 +606,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     BinningView b = carve_binning(const_cast<void *>(binning_ws), R, 0);
     if (R > 0 && binning_bytes < align_up((size_t)R * sizeof(uint32_t)) + align_up(4 * (size_t)R))
         return fail(GSR_ERR_WORKSPACE, "binning workspace too small for R=%lld", (long long)R);
+    if (acc_rows(P) >= (1u << 28)) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: P too large for the 28-bit accumulator row index");
     const size_t acc_bytes = acc_rows(P) * GSR_ACC_FLOATS * sizeof(float);
     if (bwd_bytes < acc_bytes) return fail(GSR_ERR_WORKSPACE, "backward workspace %zu < %zu", bwd_bytes, acc_bytes);
     const bool det = g_deterministic_bwd.load() != 0 && R > 0;
