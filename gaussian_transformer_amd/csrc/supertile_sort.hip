@@ -27,6 +27,9 @@
 namespace gsr {
 
 #define SS_THREADS 1024
+#ifndef SS_BIN_THREADS
+#define SS_BIN_THREADS 1024          // workgroup size of the counting / scatter kernels
+#endif
 #define SS_NSUB 512               // depth sub-buckets of one bin
 #define SS_RANK_MAX 96            // largest sub-bucket the depth-linear map may produce before the bit-linear map takes over
 
@@ -37,7 +40,7 @@ SuperSortPlan super_sort_plan(int P, int W, int H) {
     p.SY = (gridy + GSR_SS_TILES - 1) / GSR_SS_TILES;
     p.S = p.SX * p.SY;
     const long n = P > 0 ? P : 1;
-    p.chunk = 4 * SS_THREADS;
+    p.chunk = 4 * SS_BIN_THREADS;
     while ((n + p.chunk - 1) / p.chunk > 1024) p.chunk *= 2;
     p.nblk = (int)((n + p.chunk - 1) / p.chunk);
     p.ecap = (int64_t)GSR_SS_ENT_PER_G * n;
@@ -111,7 +114,7 @@ struct SsLds {
     uint32_t *spans;      // [waves][64]
     uint32_t *nbig, *nmid;   // zeroed
 };
-#define SS_LDS_LIST_WORDS(chunk) (5 * GSR_SS_MIDCAP + (chunk) + (SS_THREADS / 64) * 64)
+#define SS_LDS_LIST_WORDS(chunk) (5 * GSR_SS_MIDCAP + (chunk) + (SS_BIN_THREADS / 64) * 64)
 __device__ __forceinline__ SsLds ss_carve_lds(uint32_t *sm, int chunk, uint32_t *nbig, uint32_t *nmid) {
     SsLds l;
     l.midrec = reinterpret_cast<uint4 *>(sm);
@@ -151,19 +154,19 @@ template <bool HOT, class F>
 __device__ __forceinline__ void ss_for_chunk_entries(const SsBinArgs &a, const SsLds &l, F f) {
     const int i0 = blockIdx.x * a.chunk, i1 = min(a.P, i0 + a.chunk);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int base = i0; base < i1; base += 4 * SS_THREADS) {
+    for (int base = i0; base < i1; base += 4 * SS_BIN_THREADS) {
         // four Gaussians per thread, every load issued before the first use
         uint4 sr[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int i = base + k * SS_THREADS + (int)threadIdx.x;
+            const int i = base + k * SS_BIN_THREADS + (int)threadIdx.x;
             sr[k] = i < i1 ? a.ss_rec[i] : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t kind = sr[k].y >> 29;
             if (!kind) continue;
-            const int i = base + k * SS_THREADS + (int)threadIdx.x;
+            const int i = base + k * SS_BIN_THREADS + (int)threadIdx.x;
             if (kind == 2u) { l.big[atomicAdd(l.nbig, 1u)] = (uint32_t)i; continue; }      // at most `chunk` of them
             if (kind == 3u) {
                 const uint32_t slot = atomicAdd(l.nmid, 1u);
@@ -186,7 +189,7 @@ __device__ __forceinline__ void ss_for_chunk_entries(const SsBinArgs &a, const S
     // one wave per large rectangle; wave w takes items w, w + 16, ...  Their records are fetched 64 at a time, one item per
     // lane, and broadcast from that lane when the item's turn comes: one memory latency per 64 items instead of one each --
     // and the first batch is in flight while the medium rectangles are worked off
-    constexpr int NW = SS_THREADS / 64;
+    constexpr int NW = SS_BIN_THREADS / 64;
     for (int k0 = w, first = 1; first || k0 < nb; k0 += NW * 64, first = 0) {
         const int kl = k0 + NW * lane;
         const bool have = kl < nb;
@@ -214,7 +217,7 @@ __device__ __forceinline__ void ss_for_chunk_entries(const SsBinArgs &a, const S
             }
         }
         if (first)                                                      // medium rectangles: one per lane, densely
-            for (int k = (int)threadIdx.x; k < nm; k += SS_THREADS) ss_mid_item(l.midrec[k], l.midid[k], a.SX, f);
+            for (int k = (int)threadIdx.x; k < nm; k += SS_BIN_THREADS) ss_mid_item(l.midrec[k], l.midid[k], a.SX, f);
         const int cnt = k0 < nb ? min(64, (nb - k0 + NW - 1) / NW) : 0;    // wave-uniform
         for (int j = 0; j < cnt; j++) {
 #define SS_BC(x) __builtin_amdgcn_readlane((int)(x), j)
@@ -256,14 +259,14 @@ __device__ __forceinline__ void ss_for_chunk_entries(const SsBinArgs &a, const S
 }
 
 // ---- 1: exact entry counts: per (workgroup, super-tile) for the scatter pass, per super-tile (global) for the scan ----
-__global__ __launch_bounds__(SS_THREADS) void ss_count_kernel(SsBinArgs a) {
+__global__ __launch_bounds__(SS_BIN_THREADS) void ss_count_kernel(SsBinArgs a) {
     extern __shared__ __align__(16) uint32_t sm[];         // lists (ss_carve_lds) | h[S]
-    __shared__ uint32_t s_sum[2][SS_THREADS / 64];
+    __shared__ uint32_t s_sum[2][SS_BIN_THREADS / 64];
     __shared__ uint32_t s_nbig, s_nmid;
     const int S = a.SX * a.SY;
     const SsLds l = ss_carve_lds(sm, a.chunk, &s_nbig, &s_nmid);
     uint32_t *h = sm + SS_LDS_LIST_WORDS(a.chunk);
-    for (int b = threadIdx.x; b < S; b += SS_THREADS) h[b] = 0u;
+    for (int b = threadIdx.x; b < S; b += SS_BIN_THREADS) h[b] = 0u;
     if (threadIdx.x == 0) { s_nbig = 0u; s_nmid = 0u; }
     __syncthreads();
     uint32_t pairs = 0, ents = 0;
@@ -274,14 +277,14 @@ __global__ __launch_bounds__(SS_THREADS) void ss_count_kernel(SsBinArgs a) {
     if ((threadIdx.x & 63) == 0) { s_sum[0][threadIdx.x >> 6] = pairs; s_sum[1][threadIdx.x >> 6] = ents; }
     __syncthreads();
     uint32_t *row = a.wg_cnt + (size_t)blockIdx.x * S;
-    for (int b = threadIdx.x; b < S; b += SS_THREADS) {
+    for (int b = threadIdx.x; b < S; b += SS_BIN_THREADS) {
         const uint32_t c = h[b];
         row[b] = c;
         if (c) atomicAdd(&a.bin_cnt[b], c);
     }
     if (threadIdx.x == 0) {
         uint32_t p = 0, e = 0;
-        for (int k = 0; k < SS_THREADS / 64; k++) { p += s_sum[0][k]; e += s_sum[1][k]; }
+        for (int k = 0; k < SS_BIN_THREADS / 64; k++) { p += s_sum[0][k]; e += s_sum[1][k]; }
         if (p) atomicAdd(&a.hdr[SS_HDR_N], p);
         if (e) atomicAdd(&a.hdr[SS_HDR_E], e);
     }
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(SS_THREADS) void ss_scan_kernel(int S, uint32_t eca
 
 // ---- 3: entries to their bins (arbitrary order inside a bin; the sort of step 4 only looks at the keys).  The workgroup
 //      knows its exact count per bin from step 1 (same chunk, same code), reserves one run per touched bin and fills it ----
-__global__ __launch_bounds__(SS_THREADS) void ss_scatter_kernel(SsBinArgs a) {
+__global__ __launch_bounds__(SS_BIN_THREADS) void ss_scatter_kernel(SsBinArgs a) {
     extern __shared__ __align__(16) uint32_t sm[];         // lists (ss_carve_lds) | run base[S] | rank[S] | prs[S]
     __shared__ uint32_t s_nbig, s_nmid;
     const int S = a.SX * a.SY;
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(SS_THREADS) void ss_scatter_kernel(SsBinArgs a) {
     const SsLds l = ss_carve_lds(sm, a.chunk, &s_nbig, &s_nmid);
     uint32_t *basep = sm + SS_LDS_LIST_WORDS(a.chunk), *rank = basep + S, *prs = basep + 2 * S;
     const uint32_t *row = a.wg_cnt + (size_t)blockIdx.x * S;
-    for (int b = threadIdx.x; b < S; b += SS_THREADS) {
+    for (int b = threadIdx.x; b < S; b += SS_BIN_THREADS) {
         const uint32_t c = row[b];
         basep[b] = c ? a.bin_start[b] + atomicAdd(&a.bin_cur[b], c) : 0u;      // this workgroup's run inside the bin
         rank[b] = 0u; prs[b] = 0u;
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(SS_THREADS) void ss_scatter_kernel(SsBinArgs a) {
         atomicAdd(&prs[bin], (uint32_t)__popc(m));
     });
     __syncthreads();
-    for (int b = threadIdx.x; b < S; b += SS_THREADS)
+    for (int b = threadIdx.x; b < S; b += SS_BIN_THREADS)
         if (prs[b]) atomicAdd(&a.bin_pairs[b], prs[b]);
 }
 
@@ -594,7 +597,7 @@ hipError_t launch_super_sort_count(const GeomView &g, int P, int W, int H, int e
         const hipError_t e = ss_set_lds_attr(reinterpret_cast<const void *>(ss_count_kernel), ((size_t)GSR_SS_MAXS + SS_LDS_LIST_WORDS(GSR_SS_MAX_CHUNK)) * sizeof(uint32_t), attr);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(ss_count_kernel, dim3(pl.nblk), dim3(SS_THREADS), lds, s, ss_bin_args(g, pl, v, P, W, H, exact_cull));
+    hipLaunchKernelGGL(ss_count_kernel, dim3(pl.nblk), dim3(SS_BIN_THREADS), lds, s, ss_bin_args(g, pl, v, P, W, H, exact_cull));
     const uint32_t ecap = pl.ecap > 0xffffffffll ? 0xffffffffu : (uint32_t)pl.ecap;
     hipLaunchKernelGGL(ss_scan_kernel, dim3(1), dim3(SS_THREADS), 0, s, pl.S, ecap, v.bin_cnt, v.bin_start, v.hdr, host_out, seq);
     return hipGetLastError();
@@ -609,7 +612,7 @@ hipError_t launch_super_sort_scatter(const GeomView &g, int P, int W, int H, int
         const hipError_t e = ss_set_lds_attr(reinterpret_cast<const void *>(ss_scatter_kernel), ((size_t)3 * GSR_SS_MAXS + SS_LDS_LIST_WORDS(GSR_SS_MAX_CHUNK)) * sizeof(uint32_t), attr);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(ss_scatter_kernel, dim3(pl.nblk), dim3(SS_THREADS), lds, s, ss_bin_args(g, pl, v, P, W, H, exact_cull));
+    hipLaunchKernelGGL(ss_scatter_kernel, dim3(pl.nblk), dim3(SS_BIN_THREADS), lds, s, ss_bin_args(g, pl, v, P, W, H, exact_cull));
     return hipGetLastError();
 }
 
