@@ -86,6 +86,9 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
                     bits |= block_reachable(r0.x, r0.y, r0.z, r0.w, r1.x, invA, invC, r2.z, bxa[q], bxb[q], bya[q], byb[q]) ? (1u << q) : 0u;
             }
             live = bits != 0u;
+            // "staged with a reachable block": pergauss_bwd.hip writes plain zeros for the Gaussians nobody marks.  A plain byte store:
+            // an atomicOr into a shared flag word serialises on the splats that thousands of waves stage (config 4: 0.17 -> 0.60 ms)
+            if (live) a.touched[g] = (uint8_t)a.touch_mark;
             // the reverse pass stages the same entries against the same blocks: hand it the reachability bits
 #pragma unroll
             for (int q = 0; q < NPX; q++) {

@@ -43,6 +43,7 @@ struct DeviceState {
     std::atomic<int> bucket_fail_p{0x7fffffff};   // smallest P whose buckets overflowed even under the log map: not tried again
     std::atomic<int> depth_log_map{0};            // set once a frame overflowed a depth bucket under the linear map: log map from then on
     std::atomic<int> poll_timeouts{0};            // N read-backs whose pinned-word poll timed out (diagnostic)
+    std::atomic<uint32_t> frame_seq{0};           // forward passes so far: the mark composite_fwd leaves in GeomView::touched cycles with it
     std::mutex mu;                                // guards stage_ms and counters
     float stage_ms[GSR_NUM_STAGES] = {0};         // last profiled forward / backward on this device
     CompositeCounters *counters = nullptr;        // [2] device memory: forward, reverse (allocated on first use of count_lanes)
@@ -121,6 +122,8 @@ GeomView carve_geom(void *base, int P, size_t scan_tb, size_t dsort_tb) {
     g.dord.blkmax = (uint32_t *)take(pl.npre * sizeof(uint32_t));
     g.dord.blkent = (uint32_t *)take(pl.npre * sizeof(uint32_t));
     g.dord.comp = (uint64_t *)take(n * sizeof(uint64_t));
+    g.touched = (uint8_t *)take(n);
+    g.touch_mark = (uint32_t *)take(sizeof(uint32_t));
     g.total_bytes = off;
     return g;
 }
@@ -410,6 +413,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     pa.scales = scales; pa.rotations = rotations; pa.cov3D_precomp = cov3D_precomp;
     pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.campos = campos;
     pa.scale_modifier = scale_modifier; pa.tanfovx = tanfovx; pa.tanfovy = tanfovy; pa.radii = radii; pa.exact_cull = g_exact_cull.load(); pa.g = g;
+    pa.touch_mark = 1u + dev_state().frame_seq.fetch_add(1u) % 255u;
     HIP_TRY(launch_preprocess_fwd(pa, s), "preprocess launch");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "preprocess");
     tm.mark(1);
@@ -560,7 +564,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     CompositeArgs ca;
     ca.W = W; ca.H = H; ca.gridx = gridx; ca.gridy = gridy; ca.ranges = im.ranges; ca.point_list = b.point_list;
     ca.contrib = b.contrib; ca.contrib_stride = (size_t)(n32 > 0 ? n32 : 1);
-    ca.rec = g.rec; ca.bg = bg; ca.final_T = im.final_T; ca.n_contrib = im.n_contrib; ca.out_color = out_color;
+    ca.rec = g.rec; ca.bg = bg; ca.final_T = im.final_T; ca.n_contrib = im.n_contrib; ca.out_color = out_color; ca.touched = g.touched; ca.touch_mark = pa.touch_mark;
     ca.counters = lane_counters(0);
     HIP_TRY(launch_composite_fwd(ca, g_fwd_npx.load(), pa.exact_cull, g_wpb.load(), s), "composite launch");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "composite");
@@ -639,7 +643,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     pa.P = P; pa.D = D; pa.M = M; pa.W = W; pa.H = H; pa.means3D = means3D; pa.shs = shs; pa.colors_precomp = colors_precomp;
     pa.scales = scales; pa.rotations = rotations; pa.cov3D_precomp = cov3D_precomp; pa.viewmatrix = viewmatrix;
     pa.projmatrix = projmatrix; pa.campos = campos; pa.scale_modifier = scale_modifier; pa.tanfovx = tanfovx;
-    pa.tanfovy = tanfovy; pa.radii = radii; pa.clamped = g.clamped; pa.opac = g.opac; pa.acc = (const float *)bwd_ws; pa.hot = g.hot;
+    pa.tanfovy = tanfovy; pa.radii = radii; pa.clamped = g.clamped; pa.opac = g.opac; pa.acc = (const float *)bwd_ws; pa.hot = g.hot; pa.touched = g.touched; pa.touch_mark = g.touch_mark;
     pa.dL_dmeans2D = dL_dmeans2D; pa.dL_dopacity = dL_dopacity; pa.dL_dcolors = dL_dcolors; pa.dL_dmeans3D = dL_dmeans3D;
     pa.dL_dcov3D = dL_dcov3D; pa.dL_dsh = dL_dsh; pa.dL_dscales = dL_dscales; pa.dL_drots = dL_drots;
     HIP_TRY(launch_pergauss_bwd(pa, s), "per-Gaussian backward launch");

@@ -83,6 +83,13 @@ struct GeomView {          // per-Gaussian state, P entries each
                            //     kind 0: emits nothing; 1: zw = the 16-bit tile masks of the 2 x 2 super-tiles from that bin;
                            //     3: <= 8 rows x <= 15 columns: zw = row spans, byte k = (c0 - x0) | (c1 - x0) << 4 of row y0 + k;
                            //     2: larger rectangle (spans re-evaluated from rect / rec)
+    uint8_t *touched;      // [P] composite_fwd stores this frame's mark (1..255, *touch_mark) for every Gaussian some wave staged with a
+                           //     reachable 8x8 block.  Everything the reverse pass can give a gradient to is among those (it walks the
+                           //     same entries up to each pixel's last contributor): pergauss_bwd writes plain zeros for a Gaussian whose
+                           //     byte differs from the mark -- 91 % of the Gaussians at config 3, whose dense cloud is mostly occluded.
+                           //     Never cleared: a stale or uninitialised byte that happens to equal the mark only costs the full
+                           //     computation for that Gaussian
+    uint32_t *touch_mark;  // [1] the mark of the forward pass that filled this workspace (written by preprocess)
     uint32_t *hot;         // [P] replica code of the gradient accumulator rows (GSR_HOT_MIN_TILES above); valid where clamped has bit 7
     uint4 *ss_entries;     // [GSR_SS_ENT_PER_G * P] supertile_sort.hip: (depth bits, id, 16-bit tile mask, -) grouped by super-tile
     uint32_t *ss_wg_cnt;   // [counting workgroups][S] entries per (workgroup of 4096 Gaussians, super-tile)
@@ -135,6 +142,7 @@ struct PreprocessArgs {
     float scale_modifier, tanfovx, tanfovy;
     int *radii;
     int exact_cull;
+    uint32_t touch_mark;     // this frame's mark for GeomView::touched (1..255)
     GeomView g;
 };
 hipError_t launch_preprocess_fwd(const PreprocessArgs &a, hipStream_t s);
@@ -215,6 +223,8 @@ struct CompositeArgs {
     float *final_T;
     uint32_t *n_contrib;
     float *out_color;
+    uint8_t *touched;            // [P] GeomView::touched
+    uint32_t touch_mark;         // value to store there
 };
 hipError_t launch_composite_fwd(const CompositeArgs &a, int npx, int exact_cull, int waves_per_block, hipStream_t s);
 
@@ -256,6 +266,8 @@ struct PergaussBwdArgs {
     const uint8_t *clamped;
     const float *acc;
     const uint32_t *hot;     // [P] replica codes (GeomView::hot)
+    const uint8_t *touched;  // [P] GeomView::touched
+    const uint32_t *touch_mark;
     float *dL_dmeans2D, *dL_dopacity, *dL_dcolors, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drots;
 };
 hipError_t launch_pergauss_bwd(const PergaussBwdArgs &a, hipStream_t s);
