@@ -623,7 +623,8 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
 
     StageTimer tm(s, g_profiling.load() != 0);
     tm.mark(8);
-    HIP_TRY(hipMemsetAsync(bwd_ws, 0, det ? align_up(acc_bytes) + det_bytes : acc_bytes, s), "zero accumulators");
+    if (det) HIP_TRY(hipMemsetAsync(bwd_ws, 0, align_up(acc_bytes) + det_bytes, s), "zero accumulators");
+    else HIP_TRY(launch_zero_marked_rows(P, g.touched, g.touch_mark, (float *)bwd_ws, acc_rows(P), s), "zero accumulators");
     tm.mark(9);
     if (R > 0) {
         CompositeBwdArgs ca;

@@ -250,6 +250,7 @@ struct CompositeBwdArgs {
     const uint32_t *depth_bits;
 };
 hipError_t launch_composite_bwd(const CompositeBwdArgs &a, int npx, int exact_cull, int waves_per_block, hipStream_t s);
+hipError_t launch_zero_marked_rows(int P, const uint8_t *touched, const uint32_t *mark, float *acc, size_t rows_total, hipStream_t s);
 
 struct PergaussBwdArgs {
     int P, D, M, W, H;
