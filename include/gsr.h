@@ -58,9 +58,13 @@ int32_t gsr_abi_version(void);
 const char *gsr_last_error(void);
 
 /* Sizes (bytes) of the caller-allocated workspaces:
- *   geom_bytes : per-Gaussian state written by gsr_forward, read by gsr_backward
+ *   geom_bytes : per-Gaussian state written by gsr_forward, read by gsr_backward.  Its contents need no initialisation, and
+ *                gsr_backward must be given the workspace of the gsr_forward call it belongs to, unmodified: besides the
+ *                projected records it carries which Gaussians the forward pass composited at all (the others only get
+ *                zero gradients written) and which of them use replica accumulator rows
  *   img_bytes  : per-tile ranges + per-pixel final transmittance / last contributor
- *   bwd_bytes  : scratch used only inside gsr_backward (gradient accumulators) */
+ *   bwd_bytes  : scratch used only inside gsr_backward (gradient accumulators: one 64-byte row per Gaussian plus
+ *                P/32 + 1024 replica rows; no initialisation needed, gsr_backward clears what it uses) */
 int32_t gsr_workspace_sizes(int32_t P, int32_t W, int32_t H, size_t *geom_bytes, size_t *img_bytes, size_t *bwd_bytes);
 
 /* Size of gsr_backward's scratch workspace for a forward that rendered R pairs: the bwd_bytes of gsr_workspace_sizes,
