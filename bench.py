@@ -148,7 +148,12 @@ def main():
             with gradient_arena(ex.arena()):              # waits (on the stream) for the exchange that last used this arena
                 grads = torch.autograd.grad(color, params, grad_outputs=dL)
             if state["exchange"]:
-                ex.launch(visible=(radii > 0) if ex_sparse else None)
+                if ex_sparse:        # the Gaussians this camera composited at all (a superset of those with a gradient), else radii > 0
+                    from gaussian_transformer_amd.rasterizer import composited_mask
+                    vis = composited_mask()
+                    ex.launch(visible=vis if vis is not None else (radii > 0))
+                else:
+                    ex.launch(visible=None)
         else:
             grads = torch.autograd.grad(color, params, grad_outputs=dL)
         state["color"], state["grads"] = color, grads

@@ -724,6 +724,18 @@ int32_t gsr_mark_visible(gsr_stream_t stream, int32_t P, const float *means3D, c
     return GSR_OK;
 }
 
+int32_t gsr_composited_mask(gsr_stream_t stream, int32_t P, const void *geom_ws, size_t geom_bytes, uint8_t *out) {
+    if (P < 0 || (P > 0 && (!geom_ws || !out))) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_composited_mask: bad argument");
+    if (P == 0) return GSR_OK;
+    size_t stb = 0, dtb = 0;
+    HIP_TRY(scan_temp_bytes(P, &stb), "scan temp query");
+    HIP_TRY(depth_sort_temp_bytes(P, &dtb), "depth sort temp query");
+    const GeomView g = carve_geom(const_cast<void *>(geom_ws), P, stb, dtb);
+    if (geom_bytes < g.total_bytes) return fail(GSR_ERR_WORKSPACE, "geom workspace %zu < %zu", geom_bytes, g.total_bytes);
+    HIP_TRY(launch_composited_mask(P, g.touched, g.touch_mark, out, (hipStream_t)stream), "composited mask launch");
+    return GSR_OK;
+}
+
 int32_t gsr_debug_read_geom(gsr_stream_t stream, int32_t P, const void *geom_ws, float *depth, float *xy,
                             float *conic_opacity, float *rgb, uint32_t *tiles_touched, uint8_t *clamped) {
     hipStream_t s = (hipStream_t)stream;

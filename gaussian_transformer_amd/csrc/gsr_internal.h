@@ -146,6 +146,7 @@ struct PreprocessArgs {
     GeomView g;
 };
 hipError_t launch_preprocess_fwd(const PreprocessArgs &a, hipStream_t s);
+hipError_t launch_composited_mask(int P, const uint8_t *touched, const uint32_t *mark, uint8_t *out, hipStream_t s);
 
 hipError_t scan_temp_bytes(int P, size_t *bytes);
 

@@ -223,6 +223,18 @@ __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float *_
     present[i] = pv[2] > GSR_NEAR_Z ? 1 : 0;
 }
 
+__global__ __launch_bounds__(256) void composited_mask_kernel(int P, const uint8_t *__restrict__ touched, const uint32_t *__restrict__ mark,
+                                                             const int *__restrict__ radii_unused, uint8_t *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < P) out[i] = touched[i] == (uint8_t)*mark ? 1 : 0;
+}
+
+hipError_t launch_composited_mask(int P, const uint8_t *touched, const uint32_t *mark, uint8_t *out, hipStream_t s) {
+    if (P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(composited_mask_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, touched, mark, nullptr, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s) {
     if (P <= 0) return hipSuccess;
     hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, viewmatrix, present);

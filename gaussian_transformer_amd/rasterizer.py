@@ -164,6 +164,16 @@ class HipBackend:
             return g_means3D, g_means2D, g_sh, g_colors, g_opacity, g_scales, g_rots, g_cov3D, g_sh_rest
         return g_means3D, g_means2D, g_sh, g_colors, g_opacity, g_scales, g_rots, g_cov3D
 
+    def composited_mask(self, geom, P):
+        """bool [P]: the Gaussians the forward pass that filled `geom` composited at all (include/gsr.h gsr_composited_mask): a
+        superset of those that can receive a gradient, usually far smaller than radii > 0."""
+        dev = geom.device
+        out = torch.empty((P,), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = self.lib.gsr_composited_mask(torch.cuda.current_stream(dev).cuda_stream, P, _ptr(geom), geom.numel(), _ptr(out))
+            _lib.check(rc, "gsr_composited_mask")
+        return out.bool()
+
     def mark_visible(self, positions, viewmatrix, projmatrix):
         dev = positions.device
         if dev.type != "cuda":
@@ -179,6 +189,7 @@ class HipBackend:
 
 
 _backend = None
+_last_forward = None    # (geometry workspace, P) of the most recent forward pass, for composited_mask()
 _grad_arena = None      # optional flat float32 tensor the backward pass carves its parameter gradients from
 
 
@@ -230,6 +241,17 @@ def _dump(path, *objs):
         pass
 
 
+def composited_mask():
+    """bool [P] for the most recent GaussianRasterizer forward of this process: which Gaussians were composited at all.  Every
+    Gaussian with a non-zero gradient is among them; a data-parallel trainer can restrict its gradient exchange to the union of
+    the ranks' masks (dist.GradientExchange.launch(visible=...)).  None with a backend that does not track it."""
+    be = get_backend()
+    if _last_forward is None or not hasattr(be, "composited_mask"):
+        return None
+    geom, P = _last_forward
+    return be.composited_mask(geom, P)
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
@@ -251,6 +273,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             raise
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
+        global _last_forward
+        _last_forward = (geom, int(means3D_c.shape[0]))
         ctx.save_for_backward(colors_c, means3D_c, scales_c, rots_c, cov_c, radii, sh_c, geom, binning, img)
         ctx.mark_non_differentiable(radii)
         return color, radii
@@ -300,6 +324,8 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
         num_rendered, color, radii, geom, binning, img = be.forward(raster_settings, m3, dc, empty, op, sc, rot, empty,
                                                                     shs_rest=rest, raw_params=True)
         ctx.raster_settings, ctx.num_rendered = raster_settings, num_rendered
+        global _last_forward
+        _last_forward = (geom, int(m3.shape[0]))
         ctx.save_for_backward(m3, dc, rest, sc, rot, radii, geom, binning, img)
         ctx.mark_non_differentiable(radii)
         return color, radii

@@ -342,6 +342,33 @@ def test_forward_backward_parity(case):
     assert np.all(hg["means2D"][:, 2] == 0)
 
 
+def test_composited_mask_covers_every_gaussian_with_a_gradient():
+    """gsr_composited_mask: a superset of the Gaussians that receive a gradient, a subset of radii > 0 -- and in a dense, mostly
+    occluded cloud much smaller than that (what a data-parallel trainer exchanges)."""
+    from gaussian_transformer_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer, composited_mask
+    sc = synth.make_scene(P=60000, width=320, height=200, sh_degree=1, s0=0.03, seed=81)       # dense: most of it is occluded
+    S = oracle_scene(sc)
+    dev = "cuda"
+    t = lambda a, g=False: torch.tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev).requires_grad_(g)
+    P = sc.P
+    ps = [t(S.means3D, True), t(np.asarray(S.opacities).reshape(P, 1), True), t(S.shs, True), t(S.scales, True), t(S.rotations, True)]
+    rs = GaussianRasterizationSettings(S.H, S.W, S.tanfovx, S.tanfovy, t(S.bg), S.scale_modifier, t(np.asarray(S.viewmatrix).reshape(4, 4)),
+                                       t(np.asarray(S.projmatrix).reshape(4, 4)), S.sh_degree, t(S.campos), False, False)
+    m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
+    color, radii = GaussianRasterizer(raster_settings=rs)(means3D=ps[0], means2D=m2, shs=ps[2], opacities=ps[1], scales=ps[3], rotations=ps[4])
+    mask = composited_mask()
+    assert mask is not None and mask.shape == (P,) and mask.dtype == torch.bool
+    dL = torch.tensor(np.random.default_rng(3).normal(size=(3, S.H, S.W)).astype(np.float32), device=dev)
+    g = torch.autograd.grad(color, ps + [m2], grad_outputs=dL)
+    nz = torch.zeros(P, dtype=torch.bool, device=dev)
+    for x in g:
+        nz |= x.reshape(P, -1).abs().sum(1) > 0
+    assert not bool((nz & ~mask).any()), "a Gaussian outside the mask received a gradient"
+    assert not bool((mask & ~(radii > 0)).any())
+    assert int(mask.sum()) < int((radii > 0).sum())                  # occlusion does make it smaller here
+    assert int(nz.sum()) > 0
+
+
 def test_backward_with_replica_accumulator_rows():
     """Splats over hundreds of tiles: their waves add into replica rows of the gradient accumulator (supertile_sort.hip hands
     them out, composite_bwd.hip picks replica tile mod K, pergauss_bwd.hip folds them).  Same gradients as the oracle."""
