@@ -173,11 +173,14 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    import gc
+    gc.collect(); gc.disable()           # a collector pause inside K sub-millisecond steps would be charged to the renderer
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
