@@ -56,6 +56,7 @@ class HipBackend:
     def __init__(self):
         self.lib = _lib.load()
         self._ws_cache = {}
+        self._bin_hint = {}          # (P, W, H) -> bytes of binning workspace the last forward pass of that shape asked for
 
     def _sizes(self, P, W, H):
         key = (P, W, H)
@@ -87,9 +88,20 @@ class HipBackend:
             geom = torch.empty((gb,), **u8)
             img = torch.empty((ib,), **u8)
             holder = []
+            # The library asks for the binning workspace in the middle of the forward pass, once the device has counted the pairs,
+            # with the GPU waiting for the kernels that follow: torch.empty() there is host time on the critical path.  A buffer
+            # of the size this shape needed last time (+5 %) is set aside beforehand; the callback hands it over if it is enough.
+            key = (P, W, H)
+            hint = self._bin_hint.get(key, 0)
+            spare = torch.empty((int(hint * 1.05) + 4096,), **u8) if hint else None
+            asked = [0]
 
             def alloc(_user, nbytes):
                 try:
+                    asked[0] = int(nbytes)
+                    if spare is not None and not holder and nbytes <= spare.numel():
+                        holder.append(spare)
+                        return spare.data_ptr()
                     t = torch.empty((max(int(nbytes), 1),), **u8)
                     holder.append(t)
                     return t.data_ptr()
@@ -106,6 +118,10 @@ class HipBackend:
                 int(bool(rs.debug)), color.data_ptr(), _ptr(radii), geom.data_ptr(), gb, cb, None, img.data_ptr(), ib,
                 C.byref(n), _ptr(shs_rest), int(bool(raw_params)))
             _lib.check(rc, "gsr_forward")
+            if asked[0]:
+                self._bin_hint[key] = asked[0]
+                if len(self._bin_hint) > 64:
+                    self._bin_hint.pop(next(iter(self._bin_hint)))
             binning = holder[0] if holder else torch.empty((0,), **u8)
         return int(n.value), color, radii, geom, binning, img
 
@@ -277,12 +293,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         _last_forward = (geom, int(means3D_c.shape[0]))
         ctx.save_for_backward(colors_c, means3D_c, scales_c, rots_c, cov_c, radii, sh_c, geom, binning, img)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)      # no zero tensor for the int32 radii output on every backward (a 4 P byte fill)
         return color, radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
         be = get_backend()
         rs = ctx.raster_settings
+        if grad_out_color is None:            # materialisation is off: an unused colour output arrives as None
+            grad_out_color = torch.zeros((3, int(rs.image_height), int(rs.image_width)), dtype=torch.float32, device=ctx.saved_tensors[1].device)
         colors_c, means3D_c, scales_c, rots_c, cov_c, radii, sh_c, geom, binning, img = ctx.saved_tensors
         try:
             g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov = be.backward(
@@ -328,12 +347,16 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
         _last_forward = (geom, int(m3.shape[0]))
         ctx.save_for_backward(m3, dc, rest, sc, rot, radii, geom, binning, img)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)      # no zero tensor for the int32 radii output on every backward (a 4 P byte fill)
         return color, radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
         be = get_backend()
         m3, dc, rest, sc, rot, radii, geom, binning, img = ctx.saved_tensors
+        if grad_out_color is None:
+            rs_ = ctx.raster_settings
+            grad_out_color = torch.zeros((3, int(rs_.image_height), int(rs_.image_width)), dtype=torch.float32, device=m3.device)
         empty = m3.new_empty((0,))
         g_m3, g_m2, g_dc, _g_col, g_op, g_sc, g_rot, _g_cov, g_rest = be.backward(
             ctx.raster_settings, ctx.num_rendered, grad_out_color, m3, radii, dc, empty, sc, rot, empty, geom, binning, img,
