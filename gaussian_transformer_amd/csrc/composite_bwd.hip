@@ -17,6 +17,8 @@
 // values as rows of 68 floats (bank-conflict-free for the readers), 36 lanes each add 16 of them with
 // four ds_read_b128, two DPP steps finish, and the nine totals leave as ONE global_atomic_add_f32
 // instruction (9 lanes) into the splat's 64-byte accumulator row: one memory-side request per (wave, splat).
+#include <atomic>
+
 #include "gsr_device.h"
 #include "gsr_internal.h"
 
@@ -59,22 +61,22 @@ __device__ __forceinline__ float fold16(float a, float b) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// COUNT: instrumented instantiation (gsr_set_option("count_lanes", 1)): tallies staged records, splat visits, 8x8 block
-// visits (= 64 lane slots each), blending lanes and the reason idle lanes were idle into a.counters (CompositeCounters)
+// COUNT: instrumented instantiations (gsr_set_option("count_lanes", 1 or 2)): 1 tallies staged records, splat visits, 8x8 block
+// visits (= 64 lane slots each), blending lanes and the reason idle lanes were idle into a.counters (CompositeCounters); 2 only
+// records the wave timeline (start / end clock per work unit), at the kernel's normal speed
 // DET: deterministic mode (gsr_set_option("deterministic_bwd", 1)): instead of the float atomics, whose arrival order
 // differs from run to run, every (wave, list entry) stores its nine sums into its own slot of a.det and
 // det_reduce_kernel below adds each Gaussian's slots in a fixed order.  The in-wave reduction is order-fixed already.
-template <int NPX, bool COUNT, bool DET>
-__global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, int nblocks_padded, int /*exact_cull*/) {
+struct BwdTally { unsigned long long staged = 0, visits = 0, blocks = 0, ok = 0, past = 0, alpha = 0, red = 0, dead = 0; };
+
+// One work unit: the entries [lo, hi) of the list of `tile`, against the NPX blocks `sub` names.  hi < 0: up to the last contributor
+// of these pixels (the whole half tile, the classic decomposition).  ckslot != ~0: pixels that blended anything at or behind entry
+// hi start from the forward pass's checkpoint at that boundary instead of from the end of their list (SegView, gsr_internal.h).
+template <int NPX, int COUNT, bool DET>
+__device__ __forceinline__ void bwd_unit(const CompositeBwdArgs &a, float4 *my, const int lane, const int tile, const int sub, const int lo,
+                                         int hi, const uint32_t ckslot, BwdTally &tl) {
     constexpr int UNITS_PER_TILE = 4 / NPX;          // waves per tile
-    extern __shared__ __align__(16) float4 stage_dyn[];     // per wave: 64 records x 3 float4, then 9 x RED_STRIDE floats of reduction scratch
-    const int T = a.gridx * a.gridy;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
-    const int unit = xcd_band_unit(blockIdx.x, nblocks_padded) * wpb + wave;
-    const int tile = unit / UNITS_PER_TILE, sub = unit % UNITS_PER_TILE;
-    if (tile >= T) return;                            // wave-uniform
     const int tx = tile % a.gridx, ty = tile / a.gridx;
-    float4 *my = stage_dyn + wave * BWD_LDS_F4;
     float2 *myc = reinterpret_cast<float2 *>(my + 128);     // third array of the staged records
     float *red = reinterpret_cast<float *>(my + 128 + 32);  // [value 0..8][lane 0..63]
     const float4 *rec4 = reinterpret_cast<const float4 *>(a.rec);
@@ -115,7 +117,18 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
         max_last = max(max_last, blk_last[q]);
     }
     max_last = __builtin_amdgcn_readfirstlane(max_last);
-    if (max_last == 0) return;                        // wave-uniform
+    if (hi < 0 || hi > max_last) hi = max_last;
+    if (hi <= lo) return;                             // wave-uniform
+    if (NPX == 2 && ckslot != ~0u) {
+        // a pixel whose last contributor lies behind this unit's end starts from what the forward pass recorded there: the transmittance
+        // in front of entry hi and the colour composited from it on (a sum of per-segment colours, no cancellation)
+        const float4 *ck = a.seg.pool + (size_t)ckslot * 128 + lane;
+#pragma unroll
+        for (int q = 0; q < NPX; q++) {
+            const float4 c = ck[q * 64];
+            if (last[q] > hi) { Tr[q] = c.x; accd[q] = (c.y * d0[q] + c.z * d1[q] + c.w * d2[q]) / c.x; }
+        }
+    }
 
     // Cross-lane reduction through LDS (the LDS pipe is idle otherwise, the VALU is the bottleneck):
     // every lane stores its 9 partial sums as red[value][lane]; lane 4*value + part then adds the 16
@@ -127,9 +140,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
     const bool red_lane = rvalue < 9;
     const int slot = (red_lane && rpart == 0) ? rvalue : -1;
 
-    unsigned long long c_staged = 0, c_visits = 0, c_blocks = 0, c_ok = 0, c_past = 0, c_alpha = 0, c_red = 0, c_dead = 0;
-    for (int base = ((max_last - 1) >> 6) << 6; base >= 0; base -= 64) {
-        const int cnt = min(64, max_last - base);
+    for (int base = ((hi - 1) >> 6) << 6; base >= lo; base -= 64) {
+        const int cnt = min(64, hi - base);
         __builtin_amdgcn_wave_barrier();
         bool live = false;
         if (lane < cnt) {
@@ -152,7 +164,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
             myc[lane] = make_float2(r2.x, __uint_as_float(bits | (row << 4)));      // row < 2^28 (checked by gsr_backward)
         }
         uint64_t todo = __ballot(live);
-        if (COUNT) { c_staged += cnt; c_visits += __builtin_popcountll(todo); }
+        if (COUNT) { tl.staged += cnt; tl.visits += __builtin_popcountll(todo); }
         __builtin_amdgcn_wave_barrier();
         // The splats of the batch are visited back to front.  (Issuing the next record's LDS reads a visit ahead was measured:
         // no gain here, 10 % slower in the forward kernel -- the waves of a SIMD already cover that latency for each other.)
@@ -173,10 +185,10 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
                 const unsigned long long okm = splat_alpha(splat_power_log2(kc, dx, dy), r1.y, araw) &
                                                __builtin_amdgcn_ballot_w64(pos < last[q]);
                 any_ok |= okm;
-                if (COUNT) {
+                if (COUNT == 1) {
                     const unsigned long long mp = __ballot(!(pos < last[q]));
-                    c_blocks += 1; c_ok += __builtin_popcountll(okm); c_past += __builtin_popcountll(mp);
-                    c_alpha += __builtin_popcountll(~okm & ~mp); c_dead += okm == 0ull;
+                    tl.blocks += 1; tl.ok += __builtin_popcountll(okm); tl.past += __builtin_popcountll(mp);
+                    tl.alpha += __builtin_popcountll(~okm & ~mp); tl.dead += okm == 0ull;
                 }
 #ifdef GSR_BWD_EXEC_MASK
                 const float alpha = fminf(GSR_ALPHA_MAX, araw);
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
             for (int q = 0; q < NPX; q++)
                 if (todo_bits & (1u << q)) block_body(q);    // scalar branch per block (a fused all-blocks body: 7 % slower)
             if (any_ok == 0ull) return;                // wave-uniform: no pixel of this wave blends the splat
-            if (COUNT) c_red += 1;
+            if (COUNT == 1) tl.red += 1;
             red[0 * RED_STRIDE + lane] = v0; red[1 * RED_STRIDE + lane] = v1; red[2 * RED_STRIDE + lane] = v2;
             red[3 * RED_STRIDE + lane] = v3; red[4 * RED_STRIDE + lane] = v4; red[5 * RED_STRIDE + lane] = v5;
             red[6 * RED_STRIDE + lane] = v6; red[7 * RED_STRIDE + lane] = v7; red[8 * RED_STRIDE + lane] = v8;
@@ -242,12 +254,204 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
             visit(my[j], my[64 + j], make_float4(cj.x, 0.f, __uint_as_float(__float_as_uint(cj.y) & 15u), __uint_as_float(__float_as_uint(cj.y) >> 4)), j);
         }
     }
+}
+
+template <int COUNT>
+__device__ __forceinline__ void bwd_flush_tally(const CompositeBwdArgs &a, const BwdTally &tl, const int lane, const unsigned trace_idx,
+                                                const unsigned long long t_start) {
     if (COUNT && lane == 0 && a.counters) {
-        atomicAdd(&a.counters->staged, c_staged); atomicAdd(&a.counters->visits, c_visits);
-        atomicAdd(&a.counters->block_visits, c_blocks); atomicAdd(&a.counters->lanes_ok, c_ok);
-        atomicAdd(&a.counters->lanes_past_last, c_past); atomicAdd(&a.counters->lanes_below_alpha, c_alpha);
-        atomicAdd(&a.counters->reductions, c_red); atomicAdd(&a.counters->dead_block_visits, c_dead);
-        atomicAdd(&a.counters->waves, 1ull);
+        if (COUNT == 1) {
+            atomicAdd(&a.counters->staged, tl.staged); atomicAdd(&a.counters->visits, tl.visits);
+            atomicAdd(&a.counters->block_visits, tl.blocks); atomicAdd(&a.counters->lanes_ok, tl.ok);
+            atomicAdd(&a.counters->lanes_past_last, tl.past); atomicAdd(&a.counters->lanes_below_alpha, tl.alpha);
+            atomicAdd(&a.counters->reductions, tl.red); atomicAdd(&a.counters->dead_block_visits, tl.dead);
+            atomicAdd(&a.counters->waves, 1ull);
+        }
+        if (a.counters->trace && (unsigned long long)trace_idx < a.counters->trace_cap)
+            a.counters->trace[trace_idx] = make_uint4((uint32_t)t_start, (uint32_t)wall_clock64(), (uint32_t)tl.staged,
+                                                      (uint32_t)min(tl.visits, 4095ull) | (__builtin_amdgcn_s_getreg(30724) & 0xffffu) << 12 |   // HW_ID[15:0]: wave, simd, pipe, cu, sh, se
+                                                      (__builtin_amdgcn_s_getreg(6164) & 0xfu) << 28);                                           // XCC_ID
+    }
+}
+
+// classic decomposition: one wave per NPX blocks of a tile, XCD-banded
+template <int NPX, int COUNT, bool DET>
+__global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, int nblocks_padded, int /*exact_cull*/) {
+    constexpr int UNITS_PER_TILE = 4 / NPX;          // waves per tile
+    extern __shared__ __align__(16) float4 stage_dyn[];     // per wave: 64 records x 3 float4, then 9 x RED_STRIDE floats of reduction scratch
+    const int T = a.gridx * a.gridy;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int unit = xcd_band_unit(blockIdx.x, nblocks_padded) * wpb + wave;
+    const int tile = unit / UNITS_PER_TILE, sub = unit % UNITS_PER_TILE;
+    if (tile >= T) return;                            // wave-uniform
+    const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
+    BwdTally tl;
+    bwd_unit<NPX, COUNT, DET>(a, stage_dyn + wave * BWD_LDS_F4, lane, tile, sub, 0, -1, ~0u, tl);
+    bwd_flush_tally<COUNT>(a, tl, lane, (unsigned)unit, t_start);
+}
+
+// Persistent decomposition (2 blocks per wave): the grid's waves draw work units -- (half tile, entry range, checkpoint), listed per
+// XCD band of tiles in order of decreasing length by plan_units() below -- from the band's ticket counter; a wave whose band is
+// finished helps the next band.  Long chains start first, the short units fill the end of the kernel; neighbouring tiles stay on one
+// XCD (their splat records share its L2) as long as that XCD has work of its own.
+template <int COUNT, bool DET>
+__global__ __launch_bounds__(64) void composite_bwd_pk_kernel(CompositeBwdArgs a) {
+    extern __shared__ __align__(16) float4 stage_dyn[];
+    const int lane = threadIdx.x;
+    uint32_t *hdr = a.seg.hdr;
+    // bands in the order this wave serves them: its own first, then the other lists of its XCD (band & 7), then the other XCDs'
+    const int home = blockIdx.x & (GSR_SEG_BANDS - 1);
+    auto band_at = [&](int e) { return (((home & 7) + (e >> 2)) & 7) + 8 * (((home >> 3) + (e & 3)) & 3); };
+    int band = home;
+    // every ticket is drawn, the first one too: a ticket tied to the block index belongs to a workgroup that may not be resident yet
+    // (measured: the launch was one wave per SIMD larger than what the chip held, and those 1024 units waited for the end)
+    uint32_t ticket = 0u;
+    if (lane == 0) ticket = atomicAdd(&hdr[SEG_BTICKET + GSR_SEG_CTR_STRIDE * band], 1u);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    while (true) {                                    // wave-uniform
+        if (ticket >= hdr[SEG_BCOUNT + band]) {       // this band's list is used up (for good)
+            // Look before drawing, and look at every band at once (lane e reads the counter of the e-th band of this wave's order):
+            // when a band runs dry thousands of waves arrive here together, and their ticket atomics would queue up in one memory
+            // channel behind each other (measured: 150 us of nothing, and the waves still working stalled with them); probing the
+            // bands one after the other is a chain of 31 round trips at the end of every wave's life (measured: 10 us on a
+            // 65 us kernel).  A plain coherent read can only lag behind the counter, never run ahead of it.
+            bool has = false;
+            if (lane < GSR_SEG_BANDS) {
+                const int b = band_at(lane);
+                has = __hip_atomic_load(&hdr[SEG_BTICKET + GSR_SEG_CTR_STRIDE * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < hdr[SEG_BCOUNT + b];
+            }
+            const unsigned long long open = __ballot(has);
+            if (open == 0ull) break;
+            band = band_at(__builtin_ctzll(open));
+            uint32_t t = 0u;
+            if (lane == 0) t = atomicAdd(&hdr[SEG_BTICKET + GSR_SEG_CTR_STRIDE * band], 1u);
+            ticket = __builtin_amdgcn_readfirstlane(t);
+            continue;
+        }
+        const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
+        const size_t at = seg_list_base(a.seg, band) + ticket;
+        uint4 u = a.seg.bq[at];
+        u.x = __builtin_amdgcn_readfirstlane(u.x); u.y = __builtin_amdgcn_readfirstlane(u.y);
+        u.z = __builtin_amdgcn_readfirstlane(u.z); u.w = __builtin_amdgcn_readfirstlane(u.w);
+        BwdTally tl;
+        bwd_unit<2, COUNT, DET>(a, stage_dyn, lane, (int)(u.x >> 1), (int)(u.x & 1u), (int)u.y, (int)u.z, u.w, tl);
+        bwd_flush_tally<COUNT>(a, tl, lane, (unsigned)at, t_start);
+        // the next ticket is drawn only now: a ticket drawn ahead of time is a unit nobody else can take while this wave is still busy --
+        // measured: once all tickets were handed out, half the waves left and the rest worked off two units each
+        uint32_t nxt = 0u;
+        if (lane == 0) nxt = atomicAdd(&hdr[SEG_BTICKET + GSR_SEG_CTR_STRIDE * band], 1u);
+        ticket = __builtin_amdgcn_readfirstlane(nxt);
+    }
+}
+
+// The unit list of one band (one workgroup of 256 threads): every half tile's pieces -- [k seg, (k+1) seg) below each checkpoint the
+// forward wave took, and the top piece up to the last contributor -- counting-sorted by length, longest first.  Runs next to the
+// clearing of the accumulator rows and has to be done when that is (~9 us): everything it reads is requested up front (eight half
+// tiles per thread cover 2048 per band: 4K images), LDS atomics are issued once per wave and class.
+#define PLAN_ROUNDS 8
+__device__ void plan_units(const SegView &v, const int band) {
+    __shared__ uint32_t hist[GSR_SEG_LEN_CLASSES], cur[GSR_SEG_LEN_CLASSES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t u0 = (uint32_t)band * v.band_units, u1 = min(v.units, u0 + v.band_units);
+    const uint32_t span = (u1 > u0 ? u1 - u0 : 0u);
+    uint4 *list = v.bq + seg_list_base(v, band);
+    // requested before anything depends on them
+    uint2 in[PLAN_ROUNDS]; uint4 cka[PLAN_ROUNDS], ckb[PLAN_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < PLAN_ROUNDS; r++) {
+        const uint32_t u = u0 + r * 256u + tid;
+        const bool ok = u < u1;
+        in[r] = ok ? v.info[u] : make_uint2(0u, 0u);
+        const uint4 *cs = reinterpret_cast<const uint4 *>(v.ck_slot + (size_t)(ok ? u : u0) * 8);
+        cka[r] = cs[0]; ckb[r] = cs[1];
+    }
+    const uint32_t seg = v.hdr[SEG_SEG];
+    if (tid == 0) v.hdr[SEG_BTICKET + GSR_SEG_CTR_STRIDE * band] = 0u;
+    if (seg == 0u) {                                  // the forward pass left no lengths: the half tiles themselves, in tile order
+        for (uint32_t u = u0 + tid; u < u1; u += 256) list[u - u0] = make_uint4(u, 0u, ~0u, ~0u);
+        if (tid == 0) v.hdr[SEG_BCOUNT + band] = span;
+        return;
+    }
+    if (tid < GSR_SEG_LEN_CLASSES) { hist[tid] = 0u; cur[tid] = 0u; }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t rounds = (span + 255u) / 256u;
+    auto classify = [&](uint32_t u, const uint2 inf, uint32_t &ml, uint32_t &kt, int &cls) {
+        ml = u < u1 ? inf.x : 0u;
+        kt = ml ? min((ml - 1u) / seg, min(inf.y, (uint32_t)GSR_SEG_MAXCK)) : 0u;
+        const uint32_t top = ml - kt * seg;
+        cls = top > seg ? 0 : (top == seg ? 1 : 2 + (int)min((uint32_t)(GSR_SEG_LEN_CLASSES - 3), ((seg - top) * (GSR_SEG_LEN_CLASSES - 2)) / seg));
+    };
+    auto count_round = [&](uint32_t ml, uint32_t kt, int cls) {
+        uint32_t ks = kt;
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) ks += __shfl_xor(ks, sft);
+        if (lane == 0 && ks) atomicAdd(&hist[1], ks);
+        unsigned long long todo = __ballot(ml != 0u);
+        while (todo) {                                // wave-uniform: one round per class present in the wave
+            const int leader = __builtin_ctzll(todo);
+            const int c = __shfl(cls, leader);
+            const unsigned long long same = __ballot(ml != 0u && cls == c);
+            if (lane == leader) atomicAdd(&hist[c], (uint32_t)__builtin_popcountll(same));
+            todo &= ~same;
+        }
+    };
+    auto place_round = [&](uint32_t u, uint32_t ml, uint32_t kt, int cls, const uint4 ca, const uint4 cb) {
+        // full segments: the wave reserves the sum of its kt with one atomic, every lane takes its prefix
+        uint32_t incl = kt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        const uint32_t wsum = __shfl(incl, 63);
+        uint32_t wbase = 0u;
+        if (lane == 0 && wsum) wbase = atomicAdd(&cur[1], wsum);
+        wbase = __shfl(wbase, 0);
+        if (kt) {
+            const uint32_t p = hist[1] + wbase + (incl - kt);
+            const uint32_t slots[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+#pragma unroll
+            for (uint32_t k = 0; k < GSR_SEG_MAXCK; k++)
+                if (k < kt) list[p + k] = make_uint4(u, k * seg, (k + 1u) * seg, slots[k]);
+        }
+        unsigned long long todo = __ballot(ml != 0u);
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const int c = __shfl(cls, leader);
+            const unsigned long long same = __ballot(ml != 0u && cls == c);
+            uint32_t cbase = 0u;
+            if (lane == leader) cbase = atomicAdd(&cur[c], (uint32_t)__builtin_popcountll(same));
+            cbase = __shfl(cbase, leader);
+            if (ml != 0u && cls == c) list[hist[c] + cbase + (uint32_t)__builtin_popcountll(same & below)] = make_uint4(u, kt * seg, ml, ~0u);
+            todo &= ~same;
+        }
+    };
+    uint32_t ml[PLAN_ROUNDS], kt[PLAN_ROUNDS]; int cls[PLAN_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < PLAN_ROUNDS; r++) {
+        classify(u0 + r * 256u + tid, in[r], ml[r], kt[r], cls[r]);
+        if ((uint32_t)r < rounds) count_round(ml[r], kt[r], cls[r]);
+    }
+    for (uint32_t r = PLAN_ROUNDS; r < rounds; r++) {         // bands of more than 2048 half tiles (beyond 4K)
+        const uint32_t u = u0 + r * 256u + tid;
+        uint32_t m, k; int c;
+        classify(u, u < u1 ? v.info[u] : make_uint2(0u, 0u), m, k, c);
+        count_round(m, k, c);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0u;
+        for (int c = 0; c < GSR_SEG_LEN_CLASSES; c++) { const uint32_t h = hist[c]; hist[c] = run; run += h; }
+        v.hdr[SEG_BCOUNT + band] = run;               // <= band_units * (1 + GSR_SEG_MAXCK) by construction
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PLAN_ROUNDS; r++)
+        if ((uint32_t)r < rounds) place_round(u0 + r * 256u + tid, ml[r], kt[r], cls[r], cka[r], ckb[r]);
+    for (uint32_t r = PLAN_ROUNDS; r < rounds; r++) {
+        const uint32_t u = u0 + r * 256u + tid;
+        uint32_t m, k; int c;
+        classify(u, u < u1 ? v.info[u] : make_uint2(0u, 0u), m, k, c);
+        const uint4 *cs = reinterpret_cast<const uint4 *>(v.ck_slot + (size_t)(u < u1 ? u : u0) * 8);
+        place_round(u, m, k, c, cs[0], cs[1]);
     }
 }
 
@@ -293,30 +497,85 @@ static hipError_t launch_bwd(const CompositeBwdArgs &a, int exact_cull, int wpb,
     const int padded = (blocks + 7) / 8 * 8;
     const size_t lds = (size_t)wpb * BWD_LDS_F4 * sizeof(float4) + (size_t)g_composite_lds_pad;
     if (a.det) {
-        hipLaunchKernelGGL((composite_bwd_kernel<NPX, false, true>), dim3(padded), dim3(64 * wpb), lds, s, a, padded, exact_cull);
+        hipLaunchKernelGGL((composite_bwd_kernel<NPX, 0, true>), dim3(padded), dim3(64 * wpb), lds, s, a, padded, exact_cull);
         hipLaunchKernelGGL(det_reduce_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, 4 / NPX);
-    } else if (a.counters)
-        hipLaunchKernelGGL((composite_bwd_kernel<NPX, true, false>), dim3(padded), dim3(64 * wpb), lds, s, a, padded, exact_cull);
+    } else if (a.counters && a.count_mode == 2)
+        hipLaunchKernelGGL((composite_bwd_kernel<NPX, 2, false>), dim3(padded), dim3(64 * wpb), lds, s, a, padded, exact_cull);
+    else if (a.counters)
+        hipLaunchKernelGGL((composite_bwd_kernel<NPX, 1, false>), dim3(padded), dim3(64 * wpb), lds, s, a, padded, exact_cull);
     else
-        hipLaunchKernelGGL((composite_bwd_kernel<NPX, false, false>), dim3(padded), dim3(64 * wpb), lds, s, a, padded, exact_cull);
+        hipLaunchKernelGGL((composite_bwd_kernel<NPX, 0, false>), dim3(padded), dim3(64 * wpb), lds, s, a, padded, exact_cull);
     return hipGetLastError();
 }
 
 // The reverse pass only adds into the rows of Gaussians the forward pass marked (GeomView::touched) and into replica rows: only
 // those are cleared -- one wave-wide 16-byte store per 4 marked rows instead of a 66 P byte memset (config 3: 9 % are marked).
 __global__ __launch_bounds__(256) void zero_marked_rows_kernel(int P, const uint8_t *__restrict__ touched, const uint32_t *__restrict__ mark,
-                                                               float4 *__restrict__ acc4, size_t rows_total) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // one thread per row
+                                                               float4 *__restrict__ acc4, size_t rows_total, SegView seg, int plan_grid) {
+    // the first GSR_SEG_BANDS workgroups build the unit lists of the persistent reverse kernel instead (independent of the clearing,
+    // dispatched first so that they run alongside it)
+    const unsigned nplan = plan_grid > 0 ? GSR_SEG_BANDS : 0;
+    if (blockIdx.x < nplan) {
+        plan_units(seg, (int)blockIdx.x);
+        return;
+    }
+    const size_t i = (size_t)(blockIdx.x - nplan) * 256 + threadIdx.x;          // one thread per row
     if (i >= rows_total) return;
     if (i < (size_t)P && touched[i] != (uint8_t)*mark) return;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     acc4[4 * i] = z; acc4[4 * i + 1] = z; acc4[4 * i + 2] = z; acc4[4 * i + 3] = z;
 }
 
-hipError_t launch_zero_marked_rows(int P, const uint8_t *touched, const uint32_t *mark, float *acc, size_t rows_total, hipStream_t s) {
-    if (rows_total == 0) return hipSuccess;
-    hipLaunchKernelGGL(zero_marked_rows_kernel, dim3((unsigned)((rows_total + 255) / 256)), dim3(256), 0, s, P, touched, mark,
-                       reinterpret_cast<float4 *>(acc), rows_total);
+hipError_t launch_zero_marked_rows(int P, const uint8_t *touched, const uint32_t *mark, float *acc, size_t rows_total, const SegView &seg,
+                                   int plan_grid, hipStream_t s) {
+    const size_t blocks = (rows_total + 255) / 256 + (plan_grid > 0 ? GSR_SEG_BANDS : 0);
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(zero_marked_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, P, touched, mark, reinterpret_cast<float4 *>(acc), rows_total, seg,
+                       plan_grid);
+    return hipGetLastError();
+}
+
+// waves of the persistent kernel: exactly what the chip holds of this instantiation (occupancy query; a workgroup that is not resident
+// from the start would sit on its first ticket until another wave retires), or fewer when the image cannot have that many units
+template <typename K>
+static int resident_waves(K kernel, size_t lds, std::atomic<int> &cache) {
+    int n = cache.load();
+    if (n > 0) return n;
+    int dev = 0, cus = 256, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 16;
+    n = cus * per_cu / GSR_SEG_BANDS * GSR_SEG_BANDS;
+    if (n < GSR_SEG_BANDS) n = GSR_SEG_BANDS;
+    cache.store(n);
+    return n;
+}
+static size_t pk_lds_bytes() { return (size_t)BWD_LDS_F4 * sizeof(float4) + (size_t)g_composite_lds_pad; }
+
+int composite_bwd_persistent_grid(int T, int det, int count_mode) {
+    static std::atomic<int> c_plain{0}, c_det{0}, c_cnt{0}, c_trace{0};
+    int n;
+    if (det) n = resident_waves(composite_bwd_pk_kernel<0, true>, pk_lds_bytes(), c_det);
+    else if (count_mode == 2) n = resident_waves(composite_bwd_pk_kernel<2, false>, pk_lds_bytes(), c_trace);
+    else if (count_mode == 1) n = resident_waves(composite_bwd_pk_kernel<1, false>, pk_lds_bytes(), c_cnt);
+    else n = resident_waves(composite_bwd_pk_kernel<0, false>, pk_lds_bytes(), c_plain);
+    long long most = 2ll * T * (1 + GSR_SEG_MAXCK);              // units a frame can have at all
+    most = (most + GSR_SEG_BANDS - 1) / GSR_SEG_BANDS * GSR_SEG_BANDS;     // a multiple of the bands: wave b starts in band b & 7
+    return (int)(most < n ? (most > 0 ? most : GSR_SEG_BANDS) : n);
+}
+
+hipError_t launch_composite_bwd_persistent(const CompositeBwdArgs &a, int grid, hipStream_t s) {
+    if (a.gridx * a.gridy <= 0 || grid <= 0) return hipSuccess;
+    const size_t lds = pk_lds_bytes();
+    if (a.det) {
+        hipLaunchKernelGGL((composite_bwd_pk_kernel<0, true>), dim3(grid), dim3(64), lds, s, a);
+        hipLaunchKernelGGL(det_reduce_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, 2);
+    } else if (a.counters && a.count_mode == 2)
+        hipLaunchKernelGGL((composite_bwd_pk_kernel<2, false>), dim3(grid), dim3(64), lds, s, a);
+    else if (a.counters)
+        hipLaunchKernelGGL((composite_bwd_pk_kernel<1, false>), dim3(grid), dim3(64), lds, s, a);
+    else
+        hipLaunchKernelGGL((composite_bwd_pk_kernel<0, false>), dim3(grid), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 

@@ -27,8 +27,9 @@ __device__ __forceinline__ int xcd_band_unit_f(int b, int nblocks_padded) {
     return (b & 7) * chunk + (b >> 3);
 }
 
-// COUNT: instrumented instantiation (gsr_set_option("count_lanes", 1)), see CompositeCounters
-template <int NPX, bool COUNT>
+// COUNT: instrumented instantiations (gsr_set_option("count_lanes", 1 or 2)): 1 = lane-slot accounting (several times slower), see
+// CompositeCounters; 2 = wave timeline only (two clock reads and one store per wave: the kernel runs at its normal speed)
+template <int NPX, int COUNT>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int nblocks_padded, int exact_cull) {
     constexpr int UNITS_PER_TILE = 4 / NPX;
     extern __shared__ __align__(16) float4 stage_dyn[];     // [waves per block][64 * 3]
@@ -37,6 +38,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
     const int unit = xcd_band_unit_f(blockIdx.x, nblocks_padded) * wpb + wave;
     const int tile = unit / UNITS_PER_TILE, sub = unit % UNITS_PER_TILE;
     if (tile >= T) return;                            // wave-uniform
+    const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
     const int tx = tile % a.gridx, ty = tile / a.gridx;
     const uint2 range = a.ranges[tile];
     const int n = (int)(range.y - range.x);
@@ -68,9 +70,38 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
     }
     const uint32_t all_blocks = (1u << NPX) - 1u;
 
+    // Checkpoints for the segmented reverse pass (gsr_internal.h, SegView): every seg_len entries the wave is still alive at, it
+    // stores per pixel the transmittance so far and the colour accumulated SINCE THE PREVIOUS CHECKPOINT, then restarts the colour
+    // sums: the colour behind a boundary is later formed as a sum of per-segment colours, never as a difference of large sums.
+    const bool seg_on = NPX == 2 && a.seg_len > 0;
+    if (seg_on && unit == 0 && lane == 0) a.seg.hdr[SEG_SEG] = (uint32_t)a.seg_len;     // tells the reverse pass that units were filed
+    int next_ck = seg_on ? a.seg_len : 0x7fffffff, n_ck = 0;
+    uint32_t ck_slots = 0u;                           // lane j holds the pool slot of checkpoint j (boundary (j + 1) seg_len)
     unsigned long long c_staged = 0, c_visits = 0, c_blocks = 0, c_ok = 0, c_past = 0, c_alpha = 0, c_dead = 0;
     for (int base = 0; base < n && blk_done != all_blocks; base += 64) {
         const int cnt = min(64, n - base);
+        if (NPX == 2 && base == next_ck) {            // wave-uniform
+            next_ck = 0x7fffffff;
+            if (n_ck < GSR_SEG_MAXCK) {
+                // a slot of the band's share of the pool (one counter per band, each on its own cache line)
+                const uint32_t band = (uint32_t)unit / a.seg.band_units, share = a.seg.pool_cap / GSR_SEG_BANDS;
+                uint32_t slot = 0u;
+                if (lane == 0) slot = atomicAdd(&a.seg.hdr[SEG_POOL + GSR_SEG_CTR_STRIDE * band], 1u);
+                slot = __builtin_amdgcn_readfirstlane(slot);
+                if (slot < share) {                   // else: the share is used up, this half tile stays one unit from here on
+                    slot += band * share;
+                    float4 *ck = a.seg.pool + (size_t)slot * 128 + lane;
+#pragma unroll
+                    for (int q = 0; q < NPX; q++) {
+                        ck[q * 64] = make_float4(Tr[q], C0[q], C1[q], C2[q]);
+                        C0[q] = 0.f; C1[q] = 0.f; C2[q] = 0.f;
+                    }
+                    if (lane == n_ck) ck_slots = slot;
+                    n_ck++;
+                    next_ck = base + a.seg_len;
+                }
+            }
+        }
         __builtin_amdgcn_wave_barrier();
         bool live = false;
         if (lane < cnt) {
@@ -127,7 +158,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
                 const unsigned long long stopm = livem & __builtin_amdgcn_ballot_w64(Tn < GSR_T_MIN);
                 const unsigned long long blendm = livem & ~stopm;
                 done[q] |= stopm; any_stop |= stopm;
-                if (COUNT) {
+                if (COUNT == 1) {
                     c_blocks += 1; c_ok += __builtin_popcountll(blendm); c_past += __builtin_popcountll(done[q] & ~stopm);
                     c_alpha += __builtin_popcountll(~blendm & ~(done[q] & ~stopm)); c_dead += blendm == 0ull;
                 }
@@ -152,10 +183,38 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
         }
     }
     if (COUNT && lane == 0 && a.counters) {
+        if (COUNT == 1) {
         atomicAdd(&a.counters->staged, c_staged); atomicAdd(&a.counters->visits, c_visits);
         atomicAdd(&a.counters->block_visits, c_blocks); atomicAdd(&a.counters->lanes_ok, c_ok);
         atomicAdd(&a.counters->lanes_past_last, c_past); atomicAdd(&a.counters->lanes_below_alpha, c_alpha);
         atomicAdd(&a.counters->dead_block_visits, c_dead); atomicAdd(&a.counters->waves, 1ull);
+        }
+        if (a.counters->trace && (unsigned long long)unit < a.counters->trace_cap)
+            a.counters->trace[unit] = make_uint4((uint32_t)t_start, (uint32_t)wall_clock64(), (uint32_t)c_staged,
+                                                 (uint32_t)min(c_visits, 4095ull) | (__builtin_amdgcn_s_getreg(30724) & 0xffffu) << 12 |   // HW_ID[15:0]: wave, simd, pipe, cu, sh, se
+                                                 (__builtin_amdgcn_s_getreg(6164) & 0xfu) << 28);                                           // XCC_ID
+    }
+    if (NPX == 2 && seg_on) {
+        // back over the checkpoints: each one's colour (its own segment's) is replaced by the colour composited BEHIND its
+        // boundary, what the reverse pass starts from; the running sum ends as the pixel's whole colour
+        for (int j = n_ck - 1; j >= 0; j--) {
+            const uint32_t slot = __builtin_amdgcn_readlane(ck_slots, j);
+            float4 *ck = a.seg.pool + (size_t)slot * 128 + lane;
+#pragma unroll
+            for (int q = 0; q < NPX; q++) {
+                const float4 x = ck[q * 64];
+                ck[q * 64] = make_float4(x.x, C0[q], C1[q], C2[q]);
+                C0[q] += x.y; C1[q] += x.z; C2[q] += x.w;
+            }
+        }
+        // what the reverse pass's planner needs of this half tile: how far its pixels got, the checkpoints taken and their slots
+        int ml = 0;
+#pragma unroll
+        for (int q = 0; q < NPX; q++) ml = max(ml, (int)last[q]);
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) ml = max(ml, __shfl_xor(ml, sft));
+        if (lane < 8) a.seg.ck_slot[(size_t)unit * 8 + lane] = ck_slots;
+        if (lane == 0) a.seg.info[unit] = make_uint2((uint32_t)ml, (uint32_t)n_ck);
     }
     const size_t HW = (size_t)a.W * a.H;
     const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
@@ -179,11 +238,14 @@ static hipError_t launch_fwd(const CompositeArgs &a, int exact_cull, int wpb, hi
     const int units = T * (4 / NPX);
     const int blocks = (units + wpb - 1) / wpb;
     const int padded = (blocks + 7) / 8 * 8;
-    if (a.counters)
-        hipLaunchKernelGGL((composite_fwd_kernel<NPX, true>), dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4) + (size_t)g_composite_lds_pad, s, a,
+    if (a.counters && a.count_mode == 2)
+        hipLaunchKernelGGL((composite_fwd_kernel<NPX, 2>), dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4) + (size_t)g_composite_lds_pad, s, a,
+                           padded, exact_cull);
+    else if (a.counters)
+        hipLaunchKernelGGL((composite_fwd_kernel<NPX, 1>), dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4) + (size_t)g_composite_lds_pad, s, a,
                            padded, exact_cull);
     else
-        hipLaunchKernelGGL((composite_fwd_kernel<NPX, false>), dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4) + (size_t)g_composite_lds_pad, s, a,
+        hipLaunchKernelGGL((composite_fwd_kernel<NPX, 0>), dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4) + (size_t)g_composite_lds_pad, s, a,
                            padded, exact_cull);
     return hipGetLastError();
 }

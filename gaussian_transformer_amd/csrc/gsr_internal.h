@@ -104,10 +104,44 @@ struct GeomView {          // per-Gaussian state, P entries each
 };
 GeomView carve_geom(void *base, int P, size_t scan_temp_bytes, size_t dsort_temp_bytes);
 
+// ---- segmented reverse pass: what composite_fwd.hip leaves for composite_bwd.hip besides final_T / n_contrib ----
+// The reverse pass of a tile is a sequential chain over its list; one wave per half tile leaves the machine to a handful of
+// waves for the second half of the kernel (wave timelines, scripts/wave_trace.py).  The forward wave therefore records, every
+// `seg` list entries it is still alive at, a CHECKPOINT per pixel -- the transmittance in front of that entry and the colour
+// composited behind it -- so that the reverse pass of [k seg, (k+1) seg) can start there on its own, and leaves per half tile
+// how far its pixels got (plain stores, no atomics).  gsr_backward's first kernel (which also clears the accumulator rows) turns
+// that into work units, one list per XCD band of tiles, longest units first; the reverse kernel is persistent: a wave draws the
+// units of its own band (one ticket counter per band, 256 bytes apart: device-scope atomics on one line queue behind each other at
+// several ns apiece) and helps the other bands -- those of its own XCD first -- when its own list is empty.  Long chains start first, short units fill the end.
+#define GSR_SEG_BANDS 32        // unit lists: stripes of the image, stripe s served first by the waves of XCD s & 7 (workgroup b runs on XCD b & 7);
+                                // four lists per XCD keep the ticket counters apart (1024 draws on one line at kernel start took 7 us)
+#define GSR_SEG_MAXCK 7         // checkpoints one forward wave takes (lists beyond 8 seg entries keep one long last unit)
+#define GSR_SEG_POOL_PER_UNIT 2 // checkpoint slots (128 pixels x 16 B) in the pool per half tile; a wave that finds none left stops segmenting
+#define GSR_SEG_HDR_WORDS 8192  // the hot counters sit 256 bytes apart: device-scope atomics on lines that share a memory channel queue behind each other
+#define GSR_SEG_LEN_CLASSES 18  // planner's counting sort: 0 = remainder longer than seg, 1 = full segment, 2..17 = shorter tops, longest first
+enum { SEG_SEG = 0,             // entries per segment the forward pass used; 0: it left nothing (the reverse pass takes whole half tiles)
+       SEG_BCOUNT = 16,         // [band] units in the band's list (written by the planner, read-only afterwards)
+       SEG_POOL = 64,           // [band * GSR_SEG_CTR_STRIDE] checkpoint slots handed out of the band's share of the pool
+       SEG_BTICKET = 64 * 33,   // [band * GSR_SEG_CTR_STRIDE] ticket counter of the reverse kernel (set by every gsr_backward)
+       SEG_FTICKET = 64 * 65 }; // [band * GSR_SEG_CTR_STRIDE] ticket counter of the forward kernel
+#define GSR_SEG_CTR_STRIDE 64
+struct SegView {
+    uint32_t *hdr;           // [GSR_SEG_HDR_WORDS], zeroed by preprocess
+    float4 *pool;            // [pool_cap][128]: (T in front of the boundary, colour composited behind it) per pixel of a half tile
+    uint32_t pool_cap;       // a multiple of GSR_SEG_BANDS: band x allocates from [x, x + 1) * pool_cap / 8
+    uint2 *info;             // [units] (largest last-contributor position of the half tile's pixels, checkpoints taken)
+    uint32_t *ck_slot;       // [units][8] pool slots of the half tile's checkpoints (boundary (j + 1) seg at [j])
+    uint4 *bq;               // [GSR_SEG_BANDS][band_units * (1 + GSR_SEG_MAXCK)] reverse units (half tile, first entry, end entry or ~0, checkpoint slot at the end entry or ~0)
+    uint32_t units;          // 2 T half tiles
+    uint32_t band_units;     // half tiles per band: band of half tile u = u / band_units
+};
+__host__ __device__ static inline size_t seg_list_base(const SegView &v, int band) { return (size_t)band * v.band_units * (1 + GSR_SEG_MAXCK); }
+
 struct ImageView {
     uint2 *ranges;         // [T]
     float *final_T;        // [H*W]
     uint32_t *n_contrib;   // [H*W]
+    SegView seg;
     size_t total_bytes;
 };
 ImageView carve_image(void *base, int W, int H);
@@ -143,6 +177,7 @@ struct PreprocessArgs {
     int *radii;
     int exact_cull;
     uint32_t touch_mark;     // this frame's mark for GeomView::touched (1..255)
+    uint32_t *seg_hdr;       // SegView::hdr of the image workspace: zeroed here, with the other per-frame counters
     GeomView g;
 };
 hipError_t launch_preprocess_fwd(const PreprocessArgs &a, hipStream_t s);
@@ -209,12 +244,17 @@ hipError_t launch_super_sort_expand(const GeomView &g, const ImageView &im, uint
 // splat (reverse), lanes_below_alpha failed the alpha / power tests.
 struct CompositeCounters {
     unsigned long long staged, visits, block_visits, lanes_ok, lanes_past_last, lanes_below_alpha, reductions,
-        dead_block_visits, waves, pad[7];
+        dead_block_visits, waves;
+    uint4 *trace;                  // [trace_cap] per work unit: (start, end in 10 ns ticks of the constant-rate clock, entries staged, splat visits)
+    unsigned long long trace_cap;
+    unsigned long long pad[5];
 };
+#define GSR_TRACE_UNITS (1u << 20)
 
 struct CompositeArgs {
     int W, H, gridx, gridy;
     CompositeCounters *counters;   // NULL: plain kernel
+    int count_mode;                // with counters: 1 = lane-slot accounting, 2 = wave timeline only
     uint8_t *contrib;            // [4][contrib_stride]
     size_t contrib_stride;
     const uint2 *ranges;
@@ -226,12 +266,15 @@ struct CompositeArgs {
     float *out_color;
     uint8_t *touched;            // [P] GeomView::touched
     uint32_t touch_mark;         // value to store there
+    SegView seg;                 // checkpoints + reverse work units (used by the 2-blocks-per-wave kernel when seg_len > 0)
+    int seg_len;                 // entries per segment (multiple of 64); 0: no checkpoints, no units
 };
 hipError_t launch_composite_fwd(const CompositeArgs &a, int npx, int exact_cull, int waves_per_block, hipStream_t s);
 
 struct CompositeBwdArgs {
     int W, H, gridx, gridy;
     CompositeCounters *counters;   // NULL: plain kernel
+    int count_mode;                // with counters: 1 = lane-slot accounting, 2 = wave timeline only
     const uint8_t *contrib;      // [4][contrib_stride], from the forward pass
     size_t contrib_stride;
     const uint2 *ranges;
@@ -249,9 +292,16 @@ struct CompositeBwdArgs {
     const uint4 *rect;
     const uint32_t *tiles;
     const uint32_t *depth_bits;
+    SegView seg;             // the forward pass's checkpoints and work units (persistent kernel)
 };
 hipError_t launch_composite_bwd(const CompositeBwdArgs &a, int npx, int exact_cull, int waves_per_block, hipStream_t s);
-hipError_t launch_zero_marked_rows(int P, const uint8_t *touched, const uint32_t *mark, float *acc, size_t rows_total, hipStream_t s);
+// persistent reverse kernel (2 blocks per wave): `grid` waves draw the units the forward pass filed; the ticket counter must hold `grid`
+hipError_t launch_composite_bwd_persistent(const CompositeBwdArgs &a, int grid, hipStream_t s);
+int composite_bwd_persistent_grid(int T, int det, int count_mode);
+// clears the accumulator rows the reverse pass can add into; with plan_grid > 0 its first GSR_SEG_BANDS workgroups also build the
+// persistent reverse kernel's unit lists from what the forward pass left in `seg` and set the ticket counters for `plan_grid` waves
+hipError_t launch_zero_marked_rows(int P, const uint8_t *touched, const uint32_t *mark, float *acc, size_t rows_total, const SegView &seg,
+                                   int plan_grid, hipStream_t s);
 
 struct PergaussBwdArgs {
     int P, D, M, W, H;

@@ -16,6 +16,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
     const int i = blockIdx.x * 256 + threadIdx.x;
     for (int j = i; j < GSR_DO_ZERO_WORDS; j += gridDim.x * 256) a.g.dord.hdr[j] = 0u;    // counters of depth_order.hip
     if (i == 0) *a.g.touch_mark = a.touch_mark;           // this frame's "staged" mark, for pergauss_bwd.hip (GeomView::touched)
+    for (int j = i; j < GSR_SEG_HDR_WORDS && a.seg_hdr; j += gridDim.x * 256) a.seg_hdr[j] = 0u;    // checkpoint pool / work-unit counters of the compositing kernels (SegView)
     // no early exit: the workgroup reduces the depth extrema of its emitting Gaussians at the end.  Lanes past
     // the end recompute Gaussian P-1 and store nothing.
     const bool live = i < a.P;

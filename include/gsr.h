@@ -143,6 +143,11 @@ int32_t gsr_debug_read_binning(gsr_stream_t stream, int64_t N, int32_t W, int32_
 int32_t gsr_debug_read_image_state(gsr_stream_t stream, int32_t W, int32_t H, const void *img_ws,
                                    float *final_T /*[H,W]*/, uint32_t *n_contrib /*[H,W]*/);
 
+/* What the forward pass left for the segmented reverse pass and what the last gsr_backward made of it (tests): summary[0] = entries
+ * per segment the forward pass used (0: none), [1] = work units of the last gsr_backward's lists, [2] = checkpoint slots handed
+ * out, [3] = slots in the pool, [4] = half tiles, [5] = tickets drawn by the last persistent reverse kernel.  Synchronises. */
+int32_t gsr_debug_read_segments(gsr_stream_t stream, int32_t W, int32_t H, const void *img_ws, uint32_t *summary /*[8] host*/);
+
 /* Lane-slot accounting of the two compositing kernels (pair evaluations against the FP32 vector peak).
  * After gsr_set_option("count_lanes", 1) every gsr_forward / gsr_backward on the current device runs instrumented
  * kernels (slower) that accumulate, per direction, 16 words:
@@ -151,6 +156,10 @@ int32_t gsr_debug_read_image_state(gsr_stream_t stream, int32_t W, int32_t H, co
  *   [6] cross-lane reductions + atomics issued (reverse only)  [7] block visits in which no lane blended  [8] waves
  * This call synchronises the device, copies the words out (either pointer may be NULL) and resets them. */
 int32_t gsr_debug_read_lane_counters(uint64_t *fwd /*[16] host*/, uint64_t *bwd /*[16] host*/);
+/* Wave timeline of the last instrumented compositing launch (which: 0 forward, 1 reverse): four words per work unit
+ * (unit = tile * waves-per-tile + wave): start and end of the wave in 10 ns ticks of the device's constant-rate clock (low
+ * 32 bits), list entries staged, splat visits.  Synchronises.  Debug facility for load-balance studies (scripts/wave_trace.py). */
+int32_t gsr_debug_read_wave_trace(int32_t which, uint32_t *out /*[4 * max_units] host*/, int64_t max_units);
 
 /* Tuning knobs (process-wide).  Known options:
  *   "exact_tile_cull" (default 1): emit a (Gaussian,tile) pair only if the ellipse

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def count_once(sc, dev, opts=()):
+def count_once(sc, dev, opts=(), mode=1):
     import torch
     from gaussian_transformer_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
     from gaussian_transformer_amd.render import TorchCamera
@@ -30,7 +30,7 @@ def count_once(sc, dev, opts=()):
         sh_degree=sc.sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
     for k, v in opts:
         _lib.set_option(k, v)
-    _lib.set_option("count_lanes", 1)
+    _lib.set_option("count_lanes", mode)
     try:
         _lib.read_lane_counters()                       # reset
         means2D = torch.zeros((sc.P, 3), dtype=torch.float32, device=dev, requires_grad=True)
