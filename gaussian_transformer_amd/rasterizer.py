@@ -140,9 +140,9 @@ class HipBackend:
             has_sr = scales.numel() > 0
             arena = _grad_arena
             if arena is not None and (arena.device != dev or arena.dtype != torch.float32 or not arena.is_contiguous()
-                                      or arena.numel() < arena_floats(P, M, has_sr)):
+                                      or arena.numel() < arena_floats(P, M + Mrest, has_sr)):
                 raise _lib.GsrError("gradient arena must be a contiguous float32 tensor on the render device with "
-                                    f"at least {arena_floats(P, M, has_sr)} elements")
+                                    f"at least {arena_floats(P, M + Mrest, has_sr)} elements")
             off = [0]
 
             def out(shape):
@@ -205,8 +205,16 @@ class HipBackend:
 
 
 _backend = None
-_last_forward = None    # (geometry workspace, P) of the most recent forward pass, for composited_mask()
+_last_forward = None    # (weak reference to the geometry workspace, P) of the most recent forward pass, for composited_mask()
 _grad_arena = None      # optional flat float32 tensor the backward pass carves its parameter gradients from
+
+
+def _remember_forward(geom, P):
+    """composited_mask() without arguments refers to the most recent forward pass; a weak reference, so that the workspace (hundreds
+    of MB at 5 M Gaussians) is released with its autograd graph instead of living on until the next render."""
+    global _last_forward
+    import weakref
+    _last_forward = (weakref.ref(geom), P)
 
 
 class gradient_arena:
@@ -257,15 +265,26 @@ def _dump(path, *objs):
         pass
 
 
-def composited_mask():
-    """bool [P] for the most recent GaussianRasterizer forward of this process: which Gaussians were composited at all.  Every
-    Gaussian with a non-zero gradient is among them; a data-parallel trainer can restrict its gradient exchange to the union of
-    the ranks' masks (dist.GradientExchange.launch(visible=...)).  None with a backend that does not track it."""
+def composited_mask(image: Optional[torch.Tensor] = None):
+    """bool [P]: which Gaussians a forward pass composited at all.  Every Gaussian with a non-zero gradient is among them; a
+    data-parallel trainer can restrict its gradient exchange to the union of the ranks' masks
+    (dist.GradientExchange.launch(visible=...)).  `image`: the colour tensor a GaussianRasterizer call returned -- the mask of THAT
+    render, whatever was rendered since (several cameras per step, several devices per process).  Without it: the most recent
+    forward pass of this process, while its autograd graph is alive.  None if the backend does not track it or the render is gone."""
     be = get_backend()
-    if _last_forward is None or not hasattr(be, "composited_mask"):
+    if not hasattr(be, "composited_mask"):
         return None
-    geom, P = _last_forward
-    return be.composited_mask(geom, P)
+    if image is not None:
+        fn = image.grad_fn
+        if fn is None or not hasattr(fn, "saved_tensors") or not hasattr(fn, "gsr_geom_index"):
+            return None
+        saved = fn.saved_tensors
+        return be.composited_mask(saved[fn.gsr_geom_index], int(saved[fn.gsr_means_index].shape[0]))
+    if _last_forward is None:
+        return None
+    ref_, P = _last_forward
+    geom = ref_()
+    return None if geom is None else be.composited_mask(geom, P)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -289,9 +308,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             raise
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
-        global _last_forward
-        _last_forward = (geom, int(means3D_c.shape[0]))
+        _remember_forward(geom, int(means3D_c.shape[0]))
         ctx.save_for_backward(colors_c, means3D_c, scales_c, rots_c, cov_c, radii, sh_c, geom, binning, img)
+        ctx.gsr_geom_index, ctx.gsr_means_index = 7, 1        # composited_mask(image) finds the workspace through image.grad_fn
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)      # no zero tensor for the int32 radii output on every backward (a 4 P byte fill)
         return color, radii
@@ -343,9 +362,9 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
         num_rendered, color, radii, geom, binning, img = be.forward(raster_settings, m3, dc, empty, op, sc, rot, empty,
                                                                     shs_rest=rest, raw_params=True)
         ctx.raster_settings, ctx.num_rendered = raster_settings, num_rendered
-        global _last_forward
-        _last_forward = (geom, int(m3.shape[0]))
+        _remember_forward(geom, int(m3.shape[0]))
         ctx.save_for_backward(m3, dc, rest, sc, rot, radii, geom, binning, img)
+        ctx.gsr_geom_index, ctx.gsr_means_index = 6, 0
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)      # no zero tensor for the int32 radii output on every backward (a 4 P byte fill)
         return color, radii

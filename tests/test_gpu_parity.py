@@ -646,3 +646,37 @@ def test_forward_and_reverse_pass_take_the_same_decisions(kw):
         _lib.set_option("count_lanes", 0)
     assert c["fwd"]["lanes_ok"] > 0
     assert c["fwd"]["lanes_ok"] == c["bwd"]["lanes_ok"], (c["fwd"]["lanes_ok"], c["bwd"]["lanes_ok"])
+
+
+def test_composited_mask_belongs_to_its_render_and_undersized_fused_arena_is_refused():
+    """composited_mask(image) reads the workspace of the render that produced `image` (two renders in flight: each its own mask),
+    and the fused raw-parameter path checks the gradient arena against M = 1 + rest coefficients."""
+    from gaussian_transformer_amd import _lib
+    from gaussian_transformer_amd.model import GaussianParams
+    from gaussian_transformer_amd.rasterizer import arena_floats, composited_mask, gradient_arena
+    from gaussian_transformer_amd.render import PipelineParams, TorchCamera, render, render_fused
+    from gaussian_transformer_amd.camera import look_at_camera
+    sc = synth.make_scene(P=20000, width=160, height=96, sh_degree=1, s0=0.03, seed=82, max_sh_degree=1)
+    pc = GaussianParams.from_synthetic(sc, "cuda")
+    bg = torch.tensor(sc.bg, device="cuda")
+    cam_a = TorchCamera(sc.camera, "cuda")
+    cam_b = TorchCamera(look_at_camera(np.array([1.5, 0.0, 0.0]), np.array([0.0, 0.0, 6.0]), (0.0, -1.0, 0.0), sc.camera.FoVx, 160, 96), "cuda")
+    a = render(cam_a, pc, PipelineParams(), bg)
+    mask_a_now = composited_mask()
+    b = render(cam_b, pc, PipelineParams(), bg)
+    mask_a, mask_b = composited_mask(a["render"]), composited_mask(b["render"])
+    assert mask_a is not None and mask_b is not None
+    assert bool((mask_a == mask_a_now).all())                   # a's mask is still a's after b was rendered
+    assert bool((mask_a != mask_b).any())                        # another camera composites other Gaussians
+    assert bool((composited_mask() == mask_b).all())             # without an argument: the most recent render
+    # fused path: M + Mrest = 4 coefficients; an arena sized for the DC term only must be refused
+    f = render_fused(cam_a, pc, PipelineParams(), bg)
+    small = torch.zeros(arena_floats(sc.P, 1), device="cuda")
+    with gradient_arena(small):
+        with pytest.raises(_lib.GsrError, match="gradient arena"):
+            f["render"].sum().backward()
+    ok = torch.zeros(arena_floats(sc.P, 4), device="cuda")
+    f = render_fused(cam_a, pc, PipelineParams(), bg)
+    with gradient_arena(ok):
+        f["render"].sum().backward()
+    assert float(ok.abs().sum()) > 0

@@ -84,7 +84,7 @@ def test_checkpoint_pool_exhaustion_and_overlong_remainders(options):
     _lib.set_option("persistent_bwd", 1); _lib.set_option("segment_entries", 64)
     st = _segments_summary(S)
     assert st["n"] / (st["half_tiles"] / 2) > 64 * 12, st                  # lists of well over 8 segments
-    assert st["slots"] == st["pool"], st                                    # the pool was used up
+    assert st["slots"] == min(st["pool"], 2 * st["half_tiles"]), st       # every band used up its share of the pool (2 slots per half tile)
     h = hip_forward_backward(S, dL)
     assert np.abs(h["color"] - classic["color"]).max() < 2e-6
     for a, _ in GRADS:
