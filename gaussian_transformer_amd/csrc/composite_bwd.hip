@@ -178,11 +178,12 @@ __device__ __forceinline__ void bwd_unit(const CompositeBwdArgs &a, float4 *my, 
             const int pos = base + j;
             unsigned long long any_ok = 0ull;         // 64-bit lane mask kept in SGPRs
             const StagedConic kc = {r0.z, r0.w, r1.x};
+            const RowTerms rt = splat_row_terms(kc, r0.y - fy[0]);   // NPX == 2: both blocks lie in one row of the tile
             // body for one 8x8 block
             auto block_body = [&](int q) __attribute__((always_inline)) {
                 const float dx = r0.x - fx[q], dy = r0.y - fy[q];
                 float araw;                                          // same expression, same bits as the forward pass
-                const unsigned long long okm = splat_alpha(splat_power_log2(kc, dx, dy), r1.y, araw) &
+                const unsigned long long okm = splat_alpha(NPX == 2 ? splat_power_log2_row(kc, rt, dx) : splat_power_log2(kc, dx, dy), r1.y, araw) &
                                                __builtin_amdgcn_ballot_w64(pos < last[q]);
                 any_ok |= okm;
                 if (COUNT == 1) {
@@ -290,6 +291,66 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
     bwd_flush_tally<COUNT>(a, tl, lane, (unsigned)unit, t_start);
 }
 
+// One zero-fill unit (FillArgs): the gradient rows of the Gaussians [g0, g1) that pergauss_bwd.hip will not write -- culled, or not
+// composited by the forward pass -- set to zero, 64 Gaussians per round: their rows are contiguous in every output tensor, so the
+// wave stores whole lines, switching off the lanes whose element belongs to a Gaussian that does have a gradient.
+__device__ __forceinline__ void fill_unit(const FillArgs &f, const int lane, const int g0, const int g1) {
+    const uint32_t mark = *f.mark;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // a unit is at most four rounds of 64 Gaussians: their flags are requested together (one memory round trip per unit, not per round)
+    bool un[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int g = g0 + 64 * r + lane;
+        const bool in = g < g1 && g < f.P;
+        const int rad = in ? f.radii[g] : 1;
+        const uint32_t t = in ? (uint32_t)f.touched[g] : mark;
+        un[r] = in && !(rad > 0 && t == mark);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int base = g0 + 64 * r;
+        if (base >= g1) break;
+        const int g = base + lane;
+        const bool unmarked = un[r];
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(unmarked);
+        if (m == 0ull) continue;
+        auto bit = [&](int local) { return (m >> local) & 1ull; };
+        // three floats per Gaussian: element e of the round's 192 belongs to Gaussian e / 3
+        auto fill3 = [&](float *p) {
+            if (!p) return;
+            float *q = p + (size_t)base * 3;
+#pragma unroll
+            for (int t = 0; t < 3; t++) { const int e = lane + 64 * t; if (bit((e * 171) >> 9)) q[e] = 0.f; }
+        };
+        fill3(f.means2D); fill3(f.means3D); fill3(f.scales); fill3(f.colors);
+        if (unmarked) {
+            f.opacity[g] = 0.f;
+            if (f.rots) reinterpret_cast<float4 *>(f.rots)[g] = z4;
+        }
+        if (f.cov3D) {
+            float *q = f.cov3D + (size_t)base * 6;
+#pragma unroll
+            for (int t = 0; t < 6; t++) { const int e = lane + 64 * t; if (bit((e * 43691) >> 18)) q[e] = 0.f; }
+        }
+        auto fill_rows = [&](float *p, int fl) {     // fl floats per Gaussian
+            if (!p) return;
+            if (fl == 48 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {       // M = 16: twelve 16-byte chunks per Gaussian
+                float4 *q = reinterpret_cast<float4 *>(p) + (size_t)base * 12;
+#pragma unroll
+                for (int t = 0; t < 12; t++) { const int c = lane + 64 * t; if (bit((c * 43691) >> 19)) q[c] = z4; }
+            } else if (fl == 3) {
+                fill3(p);
+            } else {
+                float *q = p + (size_t)base * fl;
+                for (int e = lane; e < 64 * fl; e += 64) if (bit(e / fl)) q[e] = 0.f;
+            }
+        };
+        if (f.sh_rest) { fill_rows(f.sh, 3); fill_rows(f.sh_rest, 3 * (f.M - 1)); }
+        else fill_rows(f.sh, 3 * f.M);
+    }
+}
+
 // Persistent decomposition (2 blocks per wave): the grid's waves draw work units -- (half tile, entry range, checkpoint), listed per
 // XCD band of tiles in order of decreasing length by plan_units() below -- from the band's ticket counter; a wave whose band is
 // finished helps the next band.  Long chains start first, the short units fill the end of the kernel; neighbouring tiles stay on one
@@ -334,7 +395,8 @@ __global__ __launch_bounds__(64) void composite_bwd_pk_kernel(CompositeBwdArgs a
         u.x = __builtin_amdgcn_readfirstlane(u.x); u.y = __builtin_amdgcn_readfirstlane(u.y);
         u.z = __builtin_amdgcn_readfirstlane(u.z); u.w = __builtin_amdgcn_readfirstlane(u.w);
         BwdTally tl;
-        bwd_unit<2, COUNT, DET>(a, stage_dyn, lane, (int)(u.x >> 1), (int)(u.x & 1u), (int)u.y, (int)u.z, u.w, tl);
+        if (u.x == ~0u) fill_unit(a.fill, lane, (int)u.y, (int)u.z);       // wave-uniform
+        else bwd_unit<2, COUNT, DET>(a, stage_dyn, lane, (int)(u.x >> 1), (int)(u.x & 1u), (int)u.y, (int)u.z, u.w, tl);
         bwd_flush_tally<COUNT>(a, tl, lane, (unsigned)at, t_start);
         // the next ticket is drawn only now: a ticket drawn ahead of time is a unit nobody else can take while this wave is still busy --
         // measured: once all tickets were handed out, half the waves left and the rest worked off two units each
@@ -349,7 +411,7 @@ __global__ __launch_bounds__(64) void composite_bwd_pk_kernel(CompositeBwdArgs a
 // clearing of the accumulator rows and has to be done when that is (~9 us): everything it reads is requested up front (eight half
 // tiles per thread cover 2048 per band: 4K images), LDS atomics are issued once per wave and class.
 #define PLAN_ROUNDS 8
-__device__ void plan_units(const SegView &v, const int band) {
+__device__ void plan_units(const SegView &v, const int band, const int fillP, const int fill_chunk) {
     __shared__ uint32_t hist[GSR_SEG_LEN_CLASSES], cur[GSR_SEG_LEN_CLASSES];
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t u0 = (uint32_t)band * v.band_units, u1 = min(v.units, u0 + v.band_units);
@@ -367,9 +429,20 @@ __device__ void plan_units(const SegView &v, const int band) {
     }
     const uint32_t seg = v.hdr[SEG_SEG];
     if (tid == 0) v.hdr[SEG_BTICKET + GSR_SEG_CTR_STRIDE * band] = 0u;
+    // the band's share of the zero-fill units (FillArgs), behind its compositing units: chunks [c0, c1) of fill_chunk Gaussians
+    uint32_t c0 = 0u, c1 = 0u;
+    if (fill_chunk > 0 && fillP > 0) {
+        const uint32_t nc = ((uint32_t)fillP + fill_chunk - 1) / fill_chunk, per = (nc + GSR_SEG_BANDS - 1) / GSR_SEG_BANDS;
+        c0 = min(nc, (uint32_t)band * per); c1 = min(nc, c0 + min(per, (uint32_t)GSR_SEG_FILL_CAP));
+    }
+    auto append_fill = [&](uint32_t at) {
+        for (uint32_t c = c0 + tid; c < c1; c += 256)
+            list[at + (c - c0)] = make_uint4(~0u, c * fill_chunk, min((uint32_t)fillP, (c + 1u) * fill_chunk), 0u);
+    };
     if (seg == 0u) {                                  // the forward pass left no lengths: the half tiles themselves, in tile order
         for (uint32_t u = u0 + tid; u < u1; u += 256) list[u - u0] = make_uint4(u, 0u, ~0u, ~0u);
-        if (tid == 0) v.hdr[SEG_BCOUNT + band] = span;
+        append_fill(span);
+        if (tid == 0) v.hdr[SEG_BCOUNT + band] = span + (c1 - c0);
         return;
     }
     if (tid < GSR_SEG_LEN_CLASSES) { hist[tid] = 0u; cur[tid] = 0u; }
@@ -437,12 +510,15 @@ __device__ void plan_units(const SegView &v, const int band) {
         count_round(m, k, c);
     }
     __syncthreads();
+    __shared__ uint32_t n_units;
     if (tid == 0) {
         uint32_t run = 0u;
         for (int c = 0; c < GSR_SEG_LEN_CLASSES; c++) { const uint32_t h = hist[c]; hist[c] = run; run += h; }
-        v.hdr[SEG_BCOUNT + band] = run;               // <= band_units * (1 + GSR_SEG_MAXCK) by construction
+        n_units = run;                                // <= band_units * (1 + GSR_SEG_MAXCK) by construction
+        v.hdr[SEG_BCOUNT + band] = run + (c1 - c0);
     }
     __syncthreads();
+    append_fill(n_units);
 #pragma unroll
     for (int r = 0; r < PLAN_ROUNDS; r++)
         if ((uint32_t)r < rounds) place_round(u0 + r * 256u + tid, ml[r], kt[r], cls[r], cka[r], ckb[r]);
@@ -511,12 +587,13 @@ static hipError_t launch_bwd(const CompositeBwdArgs &a, int exact_cull, int wpb,
 // The reverse pass only adds into the rows of Gaussians the forward pass marked (GeomView::touched) and into replica rows: only
 // those are cleared -- one wave-wide 16-byte store per 4 marked rows instead of a 66 P byte memset (config 3: 9 % are marked).
 __global__ __launch_bounds__(256) void zero_marked_rows_kernel(int P, const uint8_t *__restrict__ touched, const uint32_t *__restrict__ mark,
-                                                               float4 *__restrict__ acc4, size_t rows_total, SegView seg, int plan_grid) {
+                                                               float4 *__restrict__ acc4, size_t rows_total, SegView seg, int plan_grid,
+                                                               int fill_chunk) {
     // the first GSR_SEG_BANDS workgroups build the unit lists of the persistent reverse kernel instead (independent of the clearing,
     // dispatched first so that they run alongside it)
     const unsigned nplan = plan_grid > 0 ? GSR_SEG_BANDS : 0;
     if (blockIdx.x < nplan) {
-        plan_units(seg, (int)blockIdx.x);
+        plan_units(seg, (int)blockIdx.x, P, fill_chunk);
         return;
     }
     const size_t i = (size_t)(blockIdx.x - nplan) * 256 + threadIdx.x;          // one thread per row
@@ -527,11 +604,11 @@ __global__ __launch_bounds__(256) void zero_marked_rows_kernel(int P, const uint
 }
 
 hipError_t launch_zero_marked_rows(int P, const uint8_t *touched, const uint32_t *mark, float *acc, size_t rows_total, const SegView &seg,
-                                   int plan_grid, hipStream_t s) {
+                                   int plan_grid, int fill_chunk, hipStream_t s) {
     const size_t blocks = (rows_total + 255) / 256 + (plan_grid > 0 ? GSR_SEG_BANDS : 0);
     if (blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(zero_marked_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, P, touched, mark, reinterpret_cast<float4 *>(acc), rows_total, seg,
-                       plan_grid);
+                       plan_grid, fill_chunk);
     return hipGetLastError();
 }
 

@@ -144,11 +144,12 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
             const uint32_t bits = __builtin_amdgcn_readfirstlane(__float_as_uint(r2.z));
             const uint32_t pos = (uint32_t)(base + j + 1);
             const StagedConic kc = {r0.z, r0.w, r1.x};
+            const RowTerms rt = splat_row_terms(kc, r0.y - fy[0]);   // NPX == 2: both blocks lie in one row of the tile
             unsigned long long any_stop = 0ull;       // lanes finishing at this splat
             auto block_body = [&](int q) __attribute__((always_inline)) {
                 const float dx = r0.x - fx[q], dy = r0.y - fy[q];
                 float araw;                                          // the one evaluation both passes share (gsr_device.h)
-                const unsigned long long okm = splat_alpha(splat_power_log2(kc, dx, dy), r1.y, araw);
+                const unsigned long long okm = splat_alpha(NPX == 2 ? splat_power_log2_row(kc, rt, dx) : splat_power_log2(kc, dx, dy), r1.y, araw);
                 const float alpha = fminf(GSR_ALPHA_MAX, araw);
                 const float aT = alpha * Tr[q];
                 const float Tn = Tr[q] - aT;                         // = T (1 - alpha)

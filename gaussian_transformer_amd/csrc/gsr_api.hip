@@ -34,6 +34,8 @@ int g_composite_lds_pad = 0;                    // debug: extra dynamic LDS byte
 static std::atomic<int> g_count_lanes{0};      // 1: instrumented compositing kernels (lane-slot accounting, slower)
 static std::atomic<int> g_deterministic_bwd{0};   // 1: fixed-order reduction of the reverse pass's partial gradients
 static std::atomic<int> g_seg_len{256};           // entries per segment of the reverse pass's work units (multiple of 64); 0: whole half tiles
+static std::atomic<int> g_fill_in_tail{0};        // 1: with the persistent reverse kernel, the zero rows of Gaussians without a gradient are written by its idle waves
+                                                  // (measured at config 3: pergauss_bwd 84 -> 62 us, but the compositing kernel + 40..66 us: off)
 static std::atomic<int> g_persistent_bwd{2};      // persistent reverse compositing kernel drawing length-ordered work units (2 blocks per wave only): 0 never, 1 always,
                                                   // 2 (default) when the image has at most GSR_PERSISTENT_MAX_TILES tiles, i.e. when its half tiles fill the chip less
                                                   // than 1.5 times over and the longest chain, not the throughput, sets the kernel's time (measured: -25 % at 800 x 800,
@@ -160,7 +162,7 @@ ImageView carve_image(void *base, int W, int H) {
     v.seg.hdr = (uint32_t *)take(GSR_SEG_HDR_WORDS * sizeof(uint32_t));
     v.seg.info = (uint2 *)take(units * sizeof(uint2));
     v.seg.ck_slot = (uint32_t *)take(units * 8 * sizeof(uint32_t));
-    v.seg.bq = (uint4 *)take((size_t)GSR_SEG_BANDS * v.seg.band_units * (1 + GSR_SEG_MAXCK) * sizeof(uint4));
+    v.seg.bq = (uint4 *)take((size_t)GSR_SEG_BANDS * seg_list_cap(v.seg) * sizeof(uint4));
     v.seg.pool = (float4 *)take((size_t)v.seg.pool_cap * 128 * sizeof(float4));
     v.total_bytes = off;
     return v;
@@ -320,6 +322,7 @@ int32_t gsr_set_option(const char *name, int32_t value) {
         if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARGUMENT, "persistent_bwd must be 0, 1 or 2");
         g_persistent_bwd.store(value); return GSR_OK;
     }
+    if (name && !strcmp(name, "fill_in_tail")) { g_fill_in_tail.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "segment_entries")) {
         if (value < 0 || value > 65536 || (value & 63)) return fail(GSR_ERR_INVALID_ARGUMENT, "segment_entries must be 0 or a multiple of 64 up to 65536");
         g_seg_len.store(value); return GSR_OK;
@@ -353,6 +356,7 @@ int32_t gsr_get_option(const char *name, int32_t *value) {
     if (name && value && !strcmp(name, "deterministic_bwd")) { *value = g_deterministic_bwd.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "persistent_bwd")) { *value = g_persistent_bwd.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "segment_entries")) { *value = g_seg_len.load(); return GSR_OK; }
+    if (name && value && !strcmp(name, "fill_in_tail")) { *value = g_fill_in_tail.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "poll_timeouts")) { *value = dev_state().poll_timeouts.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "depth_buckets")) { *value = g_depth_buckets.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "composite_waves_per_block")) { *value = g_wpb.load(); return GSR_OK; }
@@ -663,13 +667,14 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     const bool persistent = (pk_opt == 1 || (pk_opt == 2 && (long long)gridx * gridy <= GSR_PERSISTENT_MAX_TILES)) && bwd_npx == 2 &&
                             (long long)gridx * gridy <= (1 << 28) && R > 0;
     const int pk_grid = persistent ? composite_bwd_persistent_grid(gridx * gridy, det ? 1 : 0, lane_counters(1) ? g_count_lanes.load() : 0) : 0;
+    const int fill_chunk = persistent && g_fill_in_tail.load() ? seg_fill_chunk(P) : 0;       // zero-fill units in the persistent kernel's lists
 
     StageTimer tm(s, g_profiling.load() != 0);
     tm.mark(8);
     if (det) {
         HIP_TRY(hipMemsetAsync(bwd_ws, 0, align_up(acc_bytes) + det_bytes, s), "zero accumulators");
-        if (persistent) HIP_TRY(launch_zero_marked_rows(P, g.touched, g.touch_mark, (float *)bwd_ws, 0, im.seg, pk_grid, s), "unit lists");
-    } else HIP_TRY(launch_zero_marked_rows(P, g.touched, g.touch_mark, (float *)bwd_ws, acc_rows(P), im.seg, persistent ? pk_grid : 0, s), "zero accumulators");
+        if (persistent) HIP_TRY(launch_zero_marked_rows(P, g.touched, g.touch_mark, (float *)bwd_ws, 0, im.seg, pk_grid, fill_chunk, s), "unit lists");
+    } else HIP_TRY(launch_zero_marked_rows(P, g.touched, g.touch_mark, (float *)bwd_ws, acc_rows(P), im.seg, persistent ? pk_grid : 0, fill_chunk, s), "zero accumulators");
     tm.mark(9);
     if (R > 0) {
         CompositeBwdArgs ca;
@@ -681,6 +686,10 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
         ca.det = det ? (float *)((char *)bwd_ws + align_up(acc_bytes)) : nullptr;
         ca.P = P; ca.rect = g.rect; ca.tiles = g.tiles; ca.depth_bits = reinterpret_cast<const uint32_t *>(g.depth);
         ca.seg = im.seg;
+        ca.fill.P = P; ca.fill.M = M; ca.fill.chunk = fill_chunk; ca.fill.radii = radii; ca.fill.touched = g.touched; ca.fill.mark = g.touch_mark;
+        ca.fill.means2D = dL_dmeans2D; ca.fill.opacity = dL_dopacity; ca.fill.colors = dL_dcolors; ca.fill.means3D = dL_dmeans3D;
+        ca.fill.cov3D = dL_dcov3D; ca.fill.sh = shs ? dL_dsh : nullptr; ca.fill.sh_rest = shs_rest ? dL_dsh_rest : nullptr;
+        ca.fill.scales = scales ? dL_dscales : nullptr; ca.fill.rots = scales ? dL_drots : nullptr;
         if (persistent) HIP_TRY(launch_composite_bwd_persistent(ca, pk_grid, s), "composite backward launch");
         else HIP_TRY(launch_composite_bwd(ca, bwd_npx, g_exact_cull.load(), g_wpb.load(), s), "composite backward launch");
         if (debug) HIP_TRY(hipStreamSynchronize(s), "composite backward");
@@ -692,6 +701,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     pa.scales = scales; pa.rotations = rotations; pa.cov3D_precomp = cov3D_precomp; pa.viewmatrix = viewmatrix;
     pa.projmatrix = projmatrix; pa.campos = campos; pa.scale_modifier = scale_modifier; pa.tanfovx = tanfovx;
     pa.tanfovy = tanfovy; pa.radii = radii; pa.clamped = g.clamped; pa.opac = g.opac; pa.acc = (const float *)bwd_ws; pa.hot = g.hot; pa.touched = g.touched; pa.touch_mark = g.touch_mark;
+    pa.skip_unmarked = fill_chunk > 0 && R > 0 ? 1 : 0;
     pa.dL_dmeans2D = dL_dmeans2D; pa.dL_dopacity = dL_dopacity; pa.dL_dcolors = dL_dcolors; pa.dL_dmeans3D = dL_dmeans3D;
     pa.dL_dcov3D = dL_dcov3D; pa.dL_dsh = dL_dsh; pa.dL_dscales = dL_dscales; pa.dL_drots = dL_drots;
     HIP_TRY(launch_pergauss_bwd(pa, s), "per-Gaussian backward launch");

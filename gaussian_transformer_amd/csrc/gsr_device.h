@@ -293,6 +293,15 @@ __device__ __forceinline__ float splat_power_log2(const StagedConic &k, float dx
     const float t = __builtin_fmaf(k.b, dy, k.a * dx);          // a dx + b dy
     return __builtin_fmaf(k.c * dy, dy, t * dx);                // (a dx + b dy) dx + (c dy) dy
 }
+// The two blocks a wave of the default decomposition owns lie side by side: they share dy, so the terms of the exponent that do not
+// depend on dx are formed once per splat visit (u = b dy, w = (c dy) dy) and each block adds two fma: (a dx + u) dx + w.
+// The same polynomial as splat_power_log2 with another rounding; BOTH compositing passes must use the same form for a given
+// decomposition (they do: 2 blocks per wave -> this one, 1 or 4 -> splat_power_log2).
+struct RowTerms { float u, w; };
+__device__ __forceinline__ RowTerms splat_row_terms(const StagedConic &k, float dy) { return {k.b * dy, (k.c * dy) * dy}; }
+__device__ __forceinline__ float splat_power_log2_row(const StagedConic &k, const RowTerms &r, float dx) {
+    return __builtin_fmaf(__builtin_fmaf(k.a, dx, r.u), dx, r.w);
+}
 // araw = opacity * G (alpha before the 0.99 cap) and the skip decision of S9: ok = !(power > 0) && !(alpha < 1/255).
 // alpha = min(0.99, araw) < 1/255 exactly when araw < 1/255, so the decision is taken on araw and the cap is left to
 // the caller (the reverse pass caps after masking).

@@ -131,11 +131,21 @@ struct SegView {
     uint32_t pool_cap;       // a multiple of GSR_SEG_BANDS: band x allocates from [x, x + 1) * pool_cap / 8
     uint2 *info;             // [units] (largest last-contributor position of the half tile's pixels, checkpoints taken)
     uint32_t *ck_slot;       // [units][8] pool slots of the half tile's checkpoints (boundary (j + 1) seg at [j])
-    uint4 *bq;               // [GSR_SEG_BANDS][band_units * (1 + GSR_SEG_MAXCK)] reverse units (half tile, first entry, end entry or ~0, checkpoint slot at the end entry or ~0)
+    uint4 *bq;               // [GSR_SEG_BANDS][seg_list_cap] reverse units (half tile, first entry, end entry or ~0, checkpoint slot at the end entry or ~0);
+                             // behind them the band's zero-fill units (~0, first Gaussian, end Gaussian, -)
     uint32_t units;          // 2 T half tiles
     uint32_t band_units;     // half tiles per band: band of half tile u = u / band_units
 };
-__host__ __device__ static inline size_t seg_list_base(const SegView &v, int band) { return (size_t)band * v.band_units * (1 + GSR_SEG_MAXCK); }
+#define GSR_SEG_FILL_CAP 2048   // (x 32 bands x 256 Gaussians = 16 M) zero-fill units a band's list can hold behind its compositing units (FillArgs below)
+__host__ __device__ static inline size_t seg_list_cap(const SegView &v) { return (size_t)v.band_units * (1 + GSR_SEG_MAXCK) + GSR_SEG_FILL_CAP; }
+__host__ __device__ static inline size_t seg_list_base(const SegView &v, int band) { return (size_t)band * seg_list_cap(v); }
+// Gaussians per zero-fill unit: 256 (four rounds of a wave: a unit lasts a few us, so the fill really lies in the gaps of the
+// compositing work); 0 = no fill units when P / 256 of them would not fit the lists (P > 16 M: pergauss_bwd writes the zeros)
+#define GSR_SEG_FILL_CHUNK 256
+static inline int seg_fill_chunk(int P) {
+    const long long per_band = (((long long)P + GSR_SEG_FILL_CHUNK - 1) / GSR_SEG_FILL_CHUNK + GSR_SEG_BANDS - 1) / GSR_SEG_BANDS;
+    return per_band <= GSR_SEG_FILL_CAP ? GSR_SEG_FILL_CHUNK : 0;
+}
 
 struct ImageView {
     uint2 *ranges;         // [T]
@@ -271,6 +281,18 @@ struct CompositeArgs {
 };
 hipError_t launch_composite_fwd(const CompositeArgs &a, int npx, int exact_cull, int waves_per_block, hipStream_t s);
 
+// Zero-fill of the gradient rows of Gaussians that receive no gradient (not composited by the forward pass, or culled): 248 B per
+// Gaussian that gsr_backward's contract has written -- 91 % of the rows at config 3.  The persistent reverse kernel does it in
+// units of its own, listed behind each band's compositing units: the waves that find no compositing work left write zeros while the
+// last chains finish, and pergauss_bwd.hip (skip_unmarked) then touches only the Gaussians that have a gradient.
+struct FillArgs {
+    int P, M, chunk;             // chunk = Gaussians per fill unit (0: no fill units)
+    const int *radii;
+    const uint8_t *touched;
+    const uint32_t *mark;
+    float *means2D, *opacity, *colors, *means3D, *cov3D, *sh, *sh_rest, *scales, *rots;     // NULL: not an output of this call
+};
+
 struct CompositeBwdArgs {
     int W, H, gridx, gridy;
     CompositeCounters *counters;   // NULL: plain kernel
@@ -293,6 +315,7 @@ struct CompositeBwdArgs {
     const uint32_t *tiles;
     const uint32_t *depth_bits;
     SegView seg;             // the forward pass's checkpoints and work units (persistent kernel)
+    FillArgs fill;           // persistent kernel only
 };
 hipError_t launch_composite_bwd(const CompositeBwdArgs &a, int npx, int exact_cull, int waves_per_block, hipStream_t s);
 // persistent reverse kernel (2 blocks per wave): `grid` waves draw the units the forward pass filed; the ticket counter must hold `grid`
@@ -301,7 +324,7 @@ int composite_bwd_persistent_grid(int T, int det, int count_mode);
 // clears the accumulator rows the reverse pass can add into; with plan_grid > 0 its first GSR_SEG_BANDS workgroups also build the
 // persistent reverse kernel's unit lists from what the forward pass left in `seg` and set the ticket counters for `plan_grid` waves
 hipError_t launch_zero_marked_rows(int P, const uint8_t *touched, const uint32_t *mark, float *acc, size_t rows_total, const SegView &seg,
-                                   int plan_grid, hipStream_t s);
+                                   int plan_grid, int fill_chunk, hipStream_t s);
 
 struct PergaussBwdArgs {
     int P, D, M, W, H;
@@ -320,6 +343,7 @@ struct PergaussBwdArgs {
     const uint32_t *hot;     // [P] replica codes (GeomView::hot)
     const uint8_t *touched;  // [P] GeomView::touched
     const uint32_t *touch_mark;
+    int skip_unmarked;       // 1: the rows of Gaussians without a gradient have been zero-filled already (FillArgs): write nothing for them
     float *dL_dmeans2D, *dL_dopacity, *dL_dcolors, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drots;
 };
 hipError_t launch_pergauss_bwd(const PergaussBwdArgs &a, hipStream_t s);

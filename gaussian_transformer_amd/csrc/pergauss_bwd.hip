@@ -31,6 +31,10 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
     // byte != this frame's mark: no wave of the forward pass staged this Gaussian with a reachable block, so the reverse pass never met
     // it and all its gradients are 0: only the zeros are written (91 % of the Gaussians at config 3, whose dense cloud is mostly occluded)
     const bool visible = rad > 0 && tch == *a.touch_mark;
+    // skip_unmarked: the persistent reverse compositing kernel has zero-filled the rows of the Gaussians that are not `visible`
+    // (composite_bwd.hip, fill_unit: the same test on the same bytes); nothing is written for them here
+    const bool writes = visible || !a.skip_unmarked;
+    const unsigned long long wave_writes = __builtin_amdgcn_ballot_w64(writes);
     // dL/dshs rows of a whole wave (64 Gaussians x 192 B at M = 16) are contiguous in memory: the lanes put their rows into a
     // wave-private LDS tile and the wave copies the tile out with 16-byte stores at consecutive addresses (12 x 1 KiB), instead
     // of 48 dword stores per lane at a 192-byte stride that leave every 128-byte line half written 48 times over.
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
                 for (int k = 0; k < 4; k++) drot[k] = (drot[k] - q[k] * dotq) * q_inv_norm;
             }
         }
-    } else if (a.shs) {
+    } else if (a.shs && writes) {
         if (!(SPLIT) && tile_path) {
 #pragma unroll
             for (int v = 0; v < 12; v++) tile[lane * SH_TILE_ROW + v] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -250,9 +254,10 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
         for (int t = 0; t < 12; t++) {
             const int q = t * 64 + lane;
             const int g = (q * 43691) >> 19;         // q / 12 for q < 768
-            dst[q] = tile[g * SH_TILE_ROW + (q - 12 * g)];
+            if ((wave_writes >> g) & 1ull) dst[q] = tile[g * SH_TILE_ROW + (q - 12 * g)];
         }
     }
+    if (!writes) return;
     a.dL_dmeans2D[3 * si] = dm2[0]; a.dL_dmeans2D[3 * si + 1] = dm2[1]; a.dL_dmeans2D[3 * si + 2] = 0.f;
     a.dL_dopacity[si] = dop;
     if (a.dL_dcolors) { a.dL_dcolors[3 * si] = dcol[0]; a.dL_dcolors[3 * si + 1] = dcol[1]; a.dL_dcolors[3 * si + 2] = dcol[2]; }
