@@ -41,6 +41,10 @@ static std::atomic<int> g_persistent_bwd{2};      // persistent reverse composit
                                                   // than 1.5 times over and the longest chain, not the throughput, sets the kernel's time (measured: -25 % at 800 x 800,
                                                   // -10 % at 1600 x 900, +-0 at 1080p and 4K where the classic kernel's second generation of waves hides the long chains)
 #define GSR_PERSISTENT_MAX_TILES 6144
+// what gsr_forward and gsr_backward decide from the image size and the options alone: is the segmented machinery on, with what
+// segment length (the forward pass then takes checkpoints and leaves the half tiles' lengths), is the reverse kernel the persistent one
+struct SegPlan { int seg_len; bool persistent_bwd, small_image; };
+static SegPlan seg_plan(int W, int H);
 #define GSR_DEPTH_BUCKETS_MIN_P 1024           // measured at P = 10 k: 25 us against 48 us for rocPRIM sort + scan + copy-back
 
 // State that adapts to what a device has rendered lives per DEVICE, not per process: a frame with depth outliers on one
@@ -162,7 +166,8 @@ ImageView carve_image(void *base, int W, int H) {
     v.seg.hdr = (uint32_t *)take(GSR_SEG_HDR_WORDS * sizeof(uint32_t));
     v.seg.info = (uint2 *)take(units * sizeof(uint2));
     v.seg.ck_slot = (uint32_t *)take(units * 8 * sizeof(uint32_t));
-    v.seg.bq = (uint4 *)take((size_t)GSR_SEG_BANDS * seg_list_cap(v.seg) * sizeof(uint4));
+    v.seg.list_cap = (uint32_t)((size_t)v.seg.band_units * (1 + GSR_SEG_MAXCK) + GSR_SEG_FILL_CAP);
+    v.seg.bq = (uint4 *)take((size_t)GSR_SEG_BANDS * v.seg.list_cap * sizeof(uint4));
     v.seg.pool = (float4 *)take((size_t)v.seg.pool_cap * 128 * sizeof(float4));
     v.total_bytes = off;
     return v;
@@ -176,6 +181,7 @@ BinningView carve_binning(void *base, int64_t N, size_t sort_tb) {
     auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += align_up(bytes); return r; };
     b.point_list = (uint32_t *)take(n * sizeof(uint32_t));
     b.contrib = (uint8_t *)take(4 * n);
+    b.list_bytes = off;
     b.keys_sorted = (uint64_t *)take(n * sizeof(uint64_t));
     b.keys_unsorted = (uint64_t *)take(n * sizeof(uint64_t));
     b.point_list_unsorted = (uint32_t *)take(n * sizeof(uint32_t));
@@ -206,6 +212,17 @@ TileListView carve_tile_lists(void *base, const TileListPlan &pl, int64_t E) {
 }
 
 static inline int grid_dim(int px) { return (px + GSR_TILE_HOST - 1) / GSR_TILE_HOST; }
+static SegPlan seg_plan(int W, int H) {
+    SegPlan p = {0, false, false};
+    const long long T = (long long)grid_dim(W) * grid_dim(H);
+    const int pk = g_persistent_bwd.load();
+    const bool small = T <= GSR_PERSISTENT_MAX_TILES;
+    p.persistent_bwd = (pk == 1 || (pk == 2 && small)) && g_bwd_npx.load() == 2 && T <= (1 << 28);
+    const bool fwd_seg = (pk == 1 || (pk == 2 && small)) && g_fwd_npx.load() == 2 && T <= (1 << 28);
+    p.seg_len = fwd_seg ? g_seg_len.load() : 0;
+    p.small_image = small;
+    return p;
+}
 static inline int tile_bits(int W, int H) { return ceil_log2_u32((uint32_t)(grid_dim(W) * grid_dim(H))); }
 static inline int key_bits(int W, int H) { return 32 + tile_bits(W, H); }
 // temp storage that serves either sort flavour
@@ -490,7 +507,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
             n32 = h[2]; e32 = h[3];
             const int64_t N = (int64_t)n32;
             if (num_rendered) *num_rendered = N;
-            const size_t pl_bytes = align_up((size_t)(N > 0 ? N : 1) * sizeof(uint32_t)) + align_up(4 * (size_t)(N > 0 ? N : 1));   // point_list + contrib
+            const size_t pl_bytes = carve_binning(nullptr, N, 0).list_bytes;   // point_list + contrib
             char *bin_ptr = (char *)binning_alloc(binning_user, pl_bytes);
             if (!bin_ptr) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL for %zu bytes (N=%lld)", pl_bytes, (long long)N);
             b = carve_binning(bin_ptr, N, 0);
@@ -567,7 +584,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     const bool tile_lists = want_tile_lists && N > 0;
     TileListView tv;
     if (tile_lists) {             // point_list first (what backward and the debug reader expect), then the entry workspace
-        const size_t pl_bytes = align_up((size_t)N * sizeof(uint32_t)) + align_up(4 * (size_t)N);   // point_list + contrib
+        const size_t pl_bytes = carve_binning(nullptr, N, 0).list_bytes;   // point_list + contrib
         tv = carve_tile_lists(nullptr, tlp, E);
         const size_t total = pl_bytes + tv.total_bytes;
         char *bin_ptr = (char *)binning_alloc(binning_user, total);
@@ -607,8 +624,8 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     ca.counters = lane_counters(0); ca.count_mode = g_count_lanes.load();
     ca.seg = im.seg;
     // checkpoints + per-half-tile lengths for the segmented reverse pass: only where gsr_backward will use them (same rule as there)
-    const int pk_opt = g_persistent_bwd.load();
-    ca.seg_len = (g_fwd_npx.load() == 2 && (pk_opt == 1 || (pk_opt == 2 && T <= GSR_PERSISTENT_MAX_TILES)) && T <= (1 << 28)) ? g_seg_len.load() : 0;
+    const SegPlan sp = seg_plan(W, H);
+    ca.seg_len = sp.seg_len;
     HIP_TRY(launch_composite_fwd(ca, g_fwd_npx.load(), pa.exact_cull, g_wpb.load(), s), "composite launch");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "composite");
     tm.mark(-1);
@@ -650,9 +667,10 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     ImageView im = carve_image(const_cast<void *>(img_ws), W, H);
     if (geom_bytes < g.total_bytes) return fail(GSR_ERR_WORKSPACE, "geom workspace %zu < %zu", geom_bytes, g.total_bytes);
     if (img_bytes < im.total_bytes) return fail(GSR_ERR_WORKSPACE, "image workspace %zu < %zu", img_bytes, im.total_bytes);
+    const SegPlan sp = seg_plan(W, H);
     BinningView b = carve_binning(const_cast<void *>(binning_ws), R, 0);
-    if (R > 0 && binning_bytes < align_up((size_t)R * sizeof(uint32_t)) + align_up(4 * (size_t)R))
-        return fail(GSR_ERR_WORKSPACE, "binning workspace too small for R=%lld", (long long)R);
+    if (R > 0 && binning_bytes < b.list_bytes)
+        return fail(GSR_ERR_WORKSPACE, "binning workspace too small for R=%lld (%zu < %zu)", (long long)R, binning_bytes, b.list_bytes);
     if (acc_rows(P) >= (1u << 28)) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: P too large for the 28-bit accumulator row index");
     const size_t acc_bytes = acc_rows(P) * GSR_ACC_FLOATS * sizeof(float);
     if (bwd_bytes < acc_bytes) return fail(GSR_ERR_WORKSPACE, "backward workspace %zu < %zu", bwd_bytes, acc_bytes);
@@ -663,9 +681,8 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
         return fail(GSR_ERR_WORKSPACE, "deterministic_bwd: backward workspace %zu < %zu (size it with gsr_backward_workspace_bytes)", bwd_bytes,
                     align_up(acc_bytes) + det_bytes);
     const int gridx = grid_dim(W), gridy = grid_dim(H);
-    const int pk_opt = g_persistent_bwd.load();
-    const bool persistent = (pk_opt == 1 || (pk_opt == 2 && (long long)gridx * gridy <= GSR_PERSISTENT_MAX_TILES)) && bwd_npx == 2 &&
-                            (long long)gridx * gridy <= (1 << 28) && R > 0;
+    const bool persistent = sp.persistent_bwd && R > 0;
+    const SegView &segv = im.seg;
     const int pk_grid = persistent ? composite_bwd_persistent_grid(gridx * gridy, det ? 1 : 0, lane_counters(1) ? g_count_lanes.load() : 0) : 0;
     const int fill_chunk = persistent && g_fill_in_tail.load() ? seg_fill_chunk(P) : 0;       // zero-fill units in the persistent kernel's lists
 
@@ -673,8 +690,8 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     tm.mark(8);
     if (det) {
         HIP_TRY(hipMemsetAsync(bwd_ws, 0, align_up(acc_bytes) + det_bytes, s), "zero accumulators");
-        if (persistent) HIP_TRY(launch_zero_marked_rows(P, g.touched, g.touch_mark, (float *)bwd_ws, 0, im.seg, pk_grid, fill_chunk, s), "unit lists");
-    } else HIP_TRY(launch_zero_marked_rows(P, g.touched, g.touch_mark, (float *)bwd_ws, acc_rows(P), im.seg, persistent ? pk_grid : 0, fill_chunk, s), "zero accumulators");
+        if (persistent) HIP_TRY(launch_zero_marked_rows(P, g.touched, g.touch_mark, (float *)bwd_ws, 0, segv, pk_grid, fill_chunk, s), "unit lists");
+    } else HIP_TRY(launch_zero_marked_rows(P, g.touched, g.touch_mark, (float *)bwd_ws, acc_rows(P), segv, persistent ? pk_grid : 0, fill_chunk, s), "zero accumulators");
     tm.mark(9);
     if (R > 0) {
         CompositeBwdArgs ca;
@@ -685,7 +702,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
         ca.counters = lane_counters(1); ca.count_mode = g_count_lanes.load();
         ca.det = det ? (float *)((char *)bwd_ws + align_up(acc_bytes)) : nullptr;
         ca.P = P; ca.rect = g.rect; ca.tiles = g.tiles; ca.depth_bits = reinterpret_cast<const uint32_t *>(g.depth);
-        ca.seg = im.seg;
+        ca.seg = segv;
         ca.fill.P = P; ca.fill.M = M; ca.fill.chunk = fill_chunk; ca.fill.radii = radii; ca.fill.touched = g.touched; ca.fill.mark = g.touch_mark;
         ca.fill.means2D = dL_dmeans2D; ca.fill.opacity = dL_dopacity; ca.fill.colors = dL_dcolors; ca.fill.means3D = dL_dmeans3D;
         ca.fill.cov3D = dL_dcov3D; ca.fill.sh = shs ? dL_dsh : nullptr; ca.fill.sh_rest = shs_rest ? dL_dsh_rest : nullptr;

@@ -135,10 +135,10 @@ struct SegView {
                              // behind them the band's zero-fill units (~0, first Gaussian, end Gaussian, -)
     uint32_t units;          // 2 T half tiles
     uint32_t band_units;     // half tiles per band: band of half tile u = u / band_units
+    uint32_t list_cap;       // entries per band list
 };
 #define GSR_SEG_FILL_CAP 2048   // (x 32 bands x 256 Gaussians = 16 M) zero-fill units a band's list can hold behind its compositing units (FillArgs below)
-__host__ __device__ static inline size_t seg_list_cap(const SegView &v) { return (size_t)v.band_units * (1 + GSR_SEG_MAXCK) + GSR_SEG_FILL_CAP; }
-__host__ __device__ static inline size_t seg_list_base(const SegView &v, int band) { return (size_t)band * seg_list_cap(v); }
+__host__ __device__ static inline size_t seg_list_base(const SegView &v, int band) { return (size_t)band * v.list_cap; }
 // Gaussians per zero-fill unit: 256 (four rounds of a wave: a unit lasts a few us, so the fill really lies in the gaps of the
 // compositing work); 0 = no fill units when P / 256 of them would not fit the lists (P > 16 M: pergauss_bwd writes the zeros)
 #define GSR_SEG_FILL_CHUNK 256
@@ -173,6 +173,7 @@ struct BinningView {
     uint32_t *tkeys_sorted;      // = D
     void *sort_temp;
     size_t sort_temp_bytes;
+    size_t list_bytes;           // point_list + contrib: what the reverse pass needs of this workspace
     size_t total_bytes;
 };
 BinningView carve_binning(void *base, int64_t N, size_t sort_temp_bytes);
