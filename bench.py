@@ -6,10 +6,11 @@
 A "step" is one forward + backward pass of the rasterizer (GaussianRasterizer through the
 C ABI) for one 1920x1080 camera over 1 M synthetic Gaussians already resident in HBM, with a
 fixed upstream gradient dL/dimage (the metric excludes loss and optimiser).
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank renders its own camera
-over the replicated Gaussians and the 59-float/Gaussian parameter-gradient bucket is summed with
-one RCCL all-reduce inside the step (weak scaling in cameras).
-Prints ONE JSON line on rank 0.
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank renders --cameras-per-rank
+cameras (default 2) of its own over the replicated Gaussians and adds up their parameter gradients;
+the 59-float/Gaussian sums are exchanged over RCCL, waited for, and consumed by one fused Adam step,
+all inside the timed step -- a synchronous data-parallel iteration, as the reference trains
+(weak scaling in cameras).  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -48,19 +49,23 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def algorithmic_bytes(P, N, HW, K, M):
+def algorithmic_bytes(P, N, HW, K, M, n_marked=None):
     """Per-stage algorithmic bytes of one render (SURVEY.md 8d / BASELINE.md 4): every stage reads
-    its inputs once and writes its outputs once; the sort counts one read + one write of the pairs."""
+    its inputs once and writes its outputs once; the sort counts one read + one write of the pairs.
+    bwd.pergauss: every Gaussian's flags are read (6 B) and its 12 M + 56 gradient bytes written; the accumulator row, the
+    inputs and the SH row (128 + 12 K B... = 55 + 12 K + 64) are read only for the n_marked Gaussians the forward pass composited
+    (the kernel writes plain zeros for the others); n_marked = None prices all P as SURVEY 8d does."""
+    nm = P if n_marked is None else n_marked
     return {
         "fwd.preprocess": (44 + 12 * K + 75) * P,
-        "fwd.depth_order+scan": 16 * P + 8 * P,   # Gaussians sorted by depth (8 B read + 8 B written) + scan (SURVEY: 8 P)
-        "fwd.emit_keys": 20 * P + 12 * N,
-        "fwd.sort": 24 * N,               # SURVEY's figure (one read + one write of 12-byte pairs); ours moves 8-byte pairs
-        "fwd.ranges": 8 * N,
+        "fwd.lists.bin": 16 * P + 8 * P,      # entries binned per super-tile: SURVEY's depth sort (8 B read + 8 B written) + scan (8 P) figures
+        "fwd.lists.emit_keys": 20 * P + 12 * N,
+        "fwd.lists.order": 24 * N,            # SURVEY's sort figure (one read + one write of 12-byte pairs); ours moves 8-byte pairs
+        "fwd.lists.ranges": 8 * N,
         "fwd.composite": 40 * N + 20 * HW,
-        "bwd.zero_acc": 0,
+        "bwd.clear+plan": 0,
         "bwd.composite": 40 * N + 20 * HW + 36 * P,
-        "bwd.pergauss": (111 + 12 * K + 64 + 12 * M) * P,
+        "bwd.pergauss": (6 + 12 * M + 56) * P + (55 + 12 * K + 64 - 6) * nm,
     }
 
 
@@ -71,6 +76,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cfg3_synth_1M_1080p")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cameras-per-rank", type=int, default=0, help="N > 1: cameras every rank renders per step (default 2; 1 with --gpus 1)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="native tuning knob name=value (include/gsr.h gsr_set_option)")
     args = ap.parse_args()
@@ -103,14 +109,21 @@ def main():
         k, v = kv.split("=")
         _lib.set_option(k, int(v))
     sc = synth.make_config(args.config, seed=0)
-    cam_np = sc.camera
-    if world > 1:   # one camera per rank: same intrinsics, camera yawed by a rank-dependent angle about the cloud's centre
-        from gaussian_transformer_amd.camera import look_at_camera
-        ang = (rank - (world - 1) / 2.0) * math.radians(6.0)
+    B = args.cameras_per_rank if args.cameras_per_rank > 0 else (2 if world > 1 else 1)
+    from gaussian_transformer_amd.camera import look_at_camera
+
+    def rank_camera(r, b):
+        """Camera b of rank r: same intrinsics, yawed about the cloud's centre by an angle of its own."""
+        if world == 1 and B == 1:
+            return sc.camera
+        k = r * B + b
+        ang = (k - (world * B - 1) / 2.0) * math.radians(6.0 if world * B <= 16 else 96.0 / (world * B))
         centre = np.array([0.0, 0.0, 6.0])
         eye = centre + 6.0 * np.array([math.sin(ang), 0.0, -math.cos(ang)])
-        cam_np = look_at_camera(eye, centre, (0.0, -1.0, 0.0), cam_np.FoVx, cam_np.image_width, cam_np.image_height)
-    cam = TorchCamera(cam_np, dev)
+        return look_at_camera(eye, centre, (0.0, -1.0, 0.0), sc.camera.FoVx, sc.camera.image_width, sc.camera.image_height)
+    cams_np = [rank_camera(rank, b) for b in range(B)]
+    cams = [TorchCamera(c, dev) for c in cams_np]
+    cam_np, cam = cams_np[0], cams[0]
     W, H, P = cam.image_width, cam.image_height, sc.P
     D = sc.sh_degree
     M = sc.shs.shape[1]
@@ -120,50 +133,89 @@ def main():
     params = [means3D, opac, shs, scales, rots]
     dL = t(sc.dL_dimage)
     bg = t(sc.bg)
-    rs = GaussianRasterizationSettings(
-        image_height=H, image_width=W, tanfovx=cam_np.tanfovx, tanfovy=cam_np.tanfovy, bg=bg, scale_modifier=1.0,
-        viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=D,
-        campos=cam.camera_center, prefiltered=False, debug=False)
-    from gaussian_transformer_amd.rasterizer import arena_floats, gradient_arena
-    # N > 1: the backward pass writes the 59 floats/Gaussian of parameter gradients straight into a flat arena, which
-    # dist.GradientExchange sums over the ranks (RCCL over xGMI).  GSR_EXCHANGE=overlap (default): the exchange of camera k
-    # runs on a side stream while camera k+1 renders into the second arena; the last one is waited for inside the timed
-    # region.  GSR_EXCHANGE=sync: one blocking exchange per step.  GSR_ALLREDUCE=direct: two direct point-to-point phases
-    # instead of RCCL's all-reduce.  GSR_SPARSE=1: exchange only the rows of the union of the ranks' visible Gaussians.
+    settings = [GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=c_np.tanfovx, tanfovy=c_np.tanfovy, bg=bg, scale_modifier=1.0,
+        viewmatrix=c.world_view_transform, projmatrix=c.full_proj_transform, sh_degree=D,
+        campos=c.camera_center, prefiltered=False, debug=False) for c_np, c in zip(cams_np, cams)]
+    rs = settings[0]
+    from gaussian_transformer_amd.rasterizer import arena_floats, composited_mask, gradient_arena
+    # N > 1: a synchronous data-parallel iteration.  Every rank renders its B cameras; the backward pass of a camera writes the 59
+    # floats/Gaussian of parameter gradients straight into a flat arena (camera 0: the exchange arena itself, the others: a second arena
+    # that is added to it); dist.GradientExchange sums the arena over the ranks (RCCL over xGMI), the step WAITS for it, and one fused
+    # Adam launch consumes the sums (train.py:113-128 of the reference, minus its loss).  All of that is inside the timed region.
+    # GSR_ALLREDUCE=direct: two direct point-to-point phases instead of RCCL's all-reduce.  GSR_SPARSE=1: only the rows of the union of
+    # the cameras' composited masks are exchanged.  GSR_EXCHANGE=overlap additionally measures the delayed-update variant (the exchange
+    # of step k hidden behind step k+1, consumed one step late), reported beside the headline and flagged as such.
     ex = None
-    ex_mode = os.environ.get("GSR_EXCHANGE", "overlap")
     ex_sparse = os.environ.get("GSR_SPARSE", "0") == "1"
+    ex_algo = "direct" if os.environ.get("GSR_ALLREDUCE", "rccl") == "direct" else "allreduce"
+    opt = None
     if world > 1:
         from gaussian_transformer_amd.dist import GradientExchange
-        ex = GradientExchange(P, M, dev, mode=ex_mode, algo="direct" if os.environ.get("GSR_ALLREDUCE", "rccl") == "direct" else "allreduce",
-                              bucket_bytes=int(os.environ.get("GSR_BUCKET_MB", "64")) << 20)
+        from gaussian_transformer_amd.optim import HipAdam
+        ex = GradientExchange(P, M, dev, mode="sync", algo=ex_algo, bucket_bytes=int(os.environ.get("GSR_BUCKET_MB", "64")) << 20)
         assert ex.arenas[0].numel() == arena_floats(P, M)
-    state = {"exchange": True}
+        scratch_arena = torch.zeros_like(ex.arenas[0]) if B > 1 else None
+        opt = HipAdam([{"params": [p_], "lr": 0.0} for p_ in params], eps=1e-15)     # lr 0: the full Adam arithmetic, parameters (and N) unchanged
+    state = {"exchange": True, "consume": True, "ex": ex}
+
+    def render_backward(b, arena):
+        means2D = torch.zeros((P, 3), dtype=torch.float32, device=dev, requires_grad=True)
+        color, radii = GaussianRasterizer(raster_settings=settings[b])(means3D=means3D, means2D=means2D, shs=shs, opacities=opac, scales=scales, rotations=rots)
+        mask = composited_mask(color) if (ex_sparse and world > 1) else None
+        if arena is None:
+            grads = torch.autograd.grad(color, params, grad_outputs=dL)
+        else:
+            with gradient_arena(arena):
+                grads = torch.autograd.grad(color, params, grad_outputs=dL)
+        return color, grads, mask
 
     def step():
-        means2D = torch.zeros((P, 3), dtype=torch.float32, device=dev, requires_grad=True)
-        rast = GaussianRasterizer(raster_settings=rs)
-        color, radii = rast(means3D=means3D, means2D=means2D, shs=shs, opacities=opac, scales=scales, rotations=rots)
-        if world > 1:
-            with gradient_arena(ex.arena()):              # waits (on the stream) for the exchange that last used this arena
-                grads = torch.autograd.grad(color, params, grad_outputs=dL)
-            if state["exchange"]:
-                if ex_sparse:        # the Gaussians this camera composited at all (a superset of those with a gradient), else radii > 0
-                    from gaussian_transformer_amd.rasterizer import composited_mask
-                    vis = composited_mask()
-                    ex.launch(visible=vis if vis is not None else (radii > 0))
-                else:
-                    ex.launch(visible=None)
-        else:
-            grads = torch.autograd.grad(color, params, grad_outputs=dL)
+        e = state["ex"]
+        if world == 1:
+            for b in range(B):
+                color, grads, _ = render_backward(b, None)
+            state["color"], state["grads"] = color, grads
+            return
+        arena = e.arena()                                 # waits (on the stream) for the exchange that last used this arena
+        union = None
+        for b in range(B):
+            color, grads, mask = render_backward(b, arena if b == 0 else scratch_arena)
+            if b > 0:
+                arena.add_(scratch_arena)                 # this rank's cameras, summed
+            if mask is not None:
+                union = mask if union is None else (union | mask)
         state["color"], state["grads"] = color, grads
+        if state["exchange"]:
+            e.launch(visible=union)
+            if e.mode == "sync":
+                e.finish()                                # the sums are complete before anything consumes them
+        if state["consume"]:
+            v = e.views(arena if e.mode == "sync" else e.arenas[e.cur])      # overlap: the arena whose exchange was launched a step ago
+            if e.mode != "sync":
+                e.wait(e.cur)
+            for p_, n_ in zip(params, ("means3D", "opacities", "shs", "scales", "rotations")):
+                p_.grad = v[n_]
+            opt.step()
 
     def sync():
-        if ex is not None:
-            ex.finish()                                   # every outstanding exchange is part of the timed work
+        if state["ex"] is not None:
+            state["ex"].finish()                          # every outstanding exchange is part of the timed work
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def timed(k):
+        sync(); t1 = time.perf_counter()
+        for _ in range(k):
+            step()
+        sync()
+        dt_ = time.perf_counter() - t1
+        if world > 1:
+            tt_ = torch.tensor([dt_], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            dt_ = float(tt_.item())
+        return dt_
 
     # one-time initialisation outside the contract's W warm-up steps: the library creates its pinned read-back words and
     # sets kernel attributes on first use, and torch's caching allocator grows its pools on the first renders
@@ -175,41 +227,49 @@ def main():
     sync()
     import gc
     gc.collect(); gc.disable()           # a collector pause inside K sub-millisecond steps would be charged to the renderer
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
+    dt = timed(args.steps)
     gc.enable()
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
-    value = world * args.steps / dt
+    value = world * B * args.steps / dt
 
-    # ---- N > 1: what the exchange costs (outside the timed region): the same K steps without it, and K exchanges alone ----
+    # ---- N > 1: what the parts cost (outside the timed region): the same K steps without the exchange, without exchange and optimiser,
+    # K exchanges alone, and the delayed-update variant ----
     exchange = None
     if ex is not None:
         bytes_sent = ex.bytes_last
         state["exchange"] = False
+        no_ex_ms = timed(args.steps) / args.steps * 1e3
+        state["consume"] = False
+        render_ms = timed(args.steps) / args.steps * 1e3
+        state["exchange"], state["consume"] = True, True
         sync(); t1 = time.perf_counter()
         for _ in range(args.steps):
-            step()
-        sync(); compute_ms = (time.perf_counter() - t1) / args.steps * 1e3
-        state["exchange"] = True
-        sync(); t1 = time.perf_counter()
-        for _ in range(args.steps):
-            ex.arena(); ex.launch()
+            ex.arena(); ex.launch(); ex.finish()
         sync(); allreduce_ms = (time.perf_counter() - t1) / args.steps * 1e3
-        tt = torch.tensor([compute_ms, allreduce_ms], dtype=torch.float64, device=dev)
+        tt = torch.tensor([allreduce_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        compute_ms, allreduce_ms = (float(x) for x in tt.tolist())
-        exchange = {"mode": ex_mode, "algo": ex.algo, "sparse": ex_sparse, "bucket_MB": ex.bucket_floats * 4 >> 20,
+        allreduce_ms = float(tt.item())
+        delayed = None
+        if os.environ.get("GSR_EXCHANGE", "sync") == "overlap":
+            ex2 = GradientExchange(P, M, dev, mode="overlap", algo=ex_algo, bucket_bytes=ex.bucket_floats * 4)
+            state["ex"] = ex2
+            for _ in range(2):
+                step()
+            d_ms = timed(args.steps) / args.steps * 1e3
+            state["ex"] = ex
+            delayed = {"delayed_update": True, "ms_per_step": round(d_ms, 4), "renders_per_s": round(world * B / d_ms * 1e3, 2),
+                       "note": "exchange of step k runs behind step k+1 and its sums are consumed one step late: NOT what the reference's "
+                               "synchronous training does; shown for comparison only"}
+        exchange = {"mode": "sync (exchange waited for before the optimiser step, every step)", "algo": ex.algo, "sparse": ex_sparse,
+                    "bucket_MB": ex.bucket_floats * 4 >> 20, "cameras_per_rank": B,
                     "bytes_sent_per_rank_per_step": int(bytes_sent), "dense_bytes": int(ex.arenas[0].numel() * 4),
-                    "allreduce_ms": round(allreduce_ms, 4), "compute_only_ms_per_step": round(compute_ms, 4),
-                    "exposed_comm_ms": round(max(0.0, ms_per_step - compute_ms), 4),
-                    "note": "allreduce_ms = the exchange alone, back to back; exposed = step time with the exchange - step time without"}
+                    "allreduce_ms": round(allreduce_ms, 4), "step_ms_without_exchange": round(no_ex_ms, 4),
+                    "step_ms_render_only": round(render_ms, 4), "exposed_comm_ms": round(max(0.0, ms_per_step - no_ex_ms), 4),
+                    "same_work_without_exchange_renders_per_s": round(world * B / no_ex_ms * 1e3, 2),
+                    "sparse_overflows": ex.sparse_overflows, "delayed_update_variant": delayed,
+                    "note": "allreduce_ms = the exchange alone, back to back; exposed = step time with the exchange - step time without; "
+                            "render_only = without exchange and without the Adam step; no scaling curve has been measured by the builder "
+                            "(one GPU per box)"}
 
     # ---- second pass over the same K steps with per-stage hipEvents on the launch stream ----
     lib = _lib.load()
@@ -243,14 +303,22 @@ def main():
             _lib.set_option(k, int(v))
     K = (D + 1) ** 2
     HW = W * H
-    ab = algorithmic_bytes(P, N, HW, K, M)
-    kern_stages = [k for k in ab if ab[k] > 0]
+    # Gaussians the forward pass composited: the only ones bwd.pergauss reads inputs for (it writes zeros for the rest)
+    with torch.no_grad():
+        c_, _r = GaussianRasterizer(raster_settings=rs)(means3D=means3D, means2D=torch.zeros((P, 3), device=dev), shs=shs, opacities=opac,
+                                                        scales=scales, rotations=rots)
+        from gaussian_transformer_amd.rasterizer import composited_mask as _cm
+        mk = _cm()
+        n_marked = int(mk.sum().item()) if mk is not None else P
+    ab = algorithmic_bytes(P, N, HW, K, M, n_marked)
+    kern_stages = [k for k in ab if ab[k] > 0 and stage_ms.get(k, 0.0) > 0]
     dominant = max(kern_stages, key=lambda k: stage_ms.get(k, 0.0))
     dom_ms = stage_ms[dominant]
     achieved = ab[dominant] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     total_bytes = sum(ab.values())
+    total_bytes = sum(ab[k] for k in ab if stage_ms.get(k, 0.0) > 0)          # the stages that ran (the default path emits no keys, detects no ranges)
     per_stage = {k: {"ms": round(stage_ms.get(k, 0.0), 4), "alg_GB": round(ab[k] / 1e9, 4),
-                     "GBps": round(ab[k] / (stage_ms[k] * 1e-3) / 1e9, 1) if stage_ms.get(k, 0) > 0 else None} for k in ab}
+                     "GBps": round(ab[k] / (stage_ms[k] * 1e-3) / 1e9, 1) if ab[k] > 0 else None} for k in ab if stage_ms.get(k, 0.0) > 0}
     # PMC figures come from a separate rocprofv3 session (scripts/profile_round.sh -> profiles/pmc_traffic.json); they are
     # only quoted when that session ran the kernels this process runs (same native-source hash), else null + pmc_stale
     traffic = valu_busy = pmc_source = None
@@ -301,16 +369,18 @@ def main():
     limiter = ("fp32 vector issue (VALU): the compositing kernels do ~20 / ~46 flop per blended pair on "
                f"{valu.get('bwd.composite', {}).get('lane_efficiency', 0):.0%}-full wavefronts; see roofline.valu"
                if dominant.endswith("composite") else "hbm")
-    roofline = {"bound": "hbm", "limiter": limiter, "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "valu" if dominant.endswith("composite") else "hbm", "limiter": limiter, "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "valu_busy": valu_busy, "pmc_source": pmc_source,
                 "pmc_stale": pmc_stale, "kernel_ms": round(dom_ms, 4),
                 "alg_bytes_per_launch": ab[dominant], "stages": per_stage, "valu": valu,
                 "whole_path": {"alg_bytes_per_render": total_bytes,
                                "achieved_GBps": round(total_bytes * value / world / 1e9, 1),
                                "frac": round(total_bytes * value / world / 1e9 / HBM_PEAK_GBS, 4)},
+                "gaussians_composited": n_marked,
                 "note": "achieved/peak/frac price the dominant kernel against the HBM roofline as the bench contract asks (algorithmic "
-                        "SURVEY 8d bytes, N = emitted pairs); that kernel is NOT HBM-bound -- its limiter is FP32 vector issue, "
-                        "priced in roofline.valu (blended pairs x flop per pair against the 157.3 TFLOP/s vector peak)",
+                        "SURVEY 8d bytes, N = emitted pairs); `bound` names what actually limits it: FP32 vector issue, "
+                        "priced in roofline.valu (blended pairs x flop per pair against the 157.3 TFLOP/s vector peak). "
+                        "bwd.pergauss is priced with the inputs of the Gaussians it evaluates (gaussians_composited), not of all P",
                 "stage_ms_fwd_total": round(stage_ms.get("fwd.total", 0.0), 4),
                 "stage_ms_bwd_total": round(stage_ms.get("bwd.total", 0.0), 4)}
 
@@ -379,8 +449,9 @@ def main():
             "allreduce_bytes_per_step": (exchange["bytes_sent_per_rank_per_step"] if exchange else 0), "exchange": exchange,
             "config": {"workload": args.config, "gaussians": P, "width": W, "height": H, "sh_degree": D,
                        "num_rendered_pairs": int(N), "pairs_under_reference_tile_rule": int(N_ref_rule),
-                       "cameras_per_step": world,
-                       "parallelism": f"dp{world} (one camera per GPU" + (", RCCL all-reduce of gradients)" if world > 1 else ")")},
+                       "cameras_per_step": world * B,
+                       "parallelism": f"dp{world} ({B} camera{'s' if B > 1 else ''} per GPU per step" +
+                                      (", gradients summed over RCCL and consumed by a fused Adam step inside the step)" if world > 1 else ")")},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -7,6 +7,8 @@
 // Key emission is work-balanced in two levels (rows of the splat rectangles, then output pairs), each a
 // flattened walk with a 6-step ds_bpermute search over a wave-wide scan -- see emit_keys_kernel.
 #include <cstring>  // ROCm 7.2 rocprim/texture_cache_iterator.hpp uses memset without including it
+#include <mutex>
+
 #include <rocprim/rocprim.hpp>
 
 #include "gsr_device.h"
@@ -14,11 +16,43 @@
 
 namespace gsr {
 
+// rocPRIM's temp-size queries look the device up on every call (microseconds each, three per gsr_forward and per gsr_backward: a
+// tenth of a small scene's host time); the answers depend on P and the device only
+struct TempSizeCache {
+    std::mutex mu;
+    struct E { int dev, P; size_t scan, dsort; bool has_scan, has_dsort; } e[8] = {};
+    int next = 0;
+    E *find(int dev, int P) {
+        for (auto &x : e) if ((x.has_scan || x.has_dsort) && x.dev == dev && x.P == P) return &x;
+        return nullptr;
+    }
+    E *slot(int dev, int P) {
+        E *x = find(dev, P);
+        if (x) return x;
+        x = &e[next]; next = (next + 1) % 8;
+        *x = E{dev, P, 0, 0, false, false};
+        return x;
+    }
+};
+static TempSizeCache g_tsc;
+static int current_device() { int d = 0; return hipGetDevice(&d) == hipSuccess ? d : 0; }
+
 hipError_t scan_temp_bytes(int P, size_t *bytes) {
+    const int dev = current_device();
+    {
+        std::lock_guard<std::mutex> lk(g_tsc.mu);
+        TempSizeCache::E *x = g_tsc.find(dev, P);
+        if (x && x->has_scan) { *bytes = x->scan; return hipSuccess; }
+    }
     size_t tb = 0;
     hipError_t e = rocprim::inclusive_scan(nullptr, tb, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                            (size_t)(P > 0 ? P : 1), rocprim::plus<uint32_t>(), (hipStream_t)0, false);
     *bytes = tb;
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_tsc.mu);
+        TempSizeCache::E *x = g_tsc.slot(dev, P);
+        x->scan = tb; x->has_scan = true;
+    }
     return e;
 }
 
@@ -53,6 +87,12 @@ using DepthSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocp
 #define GSR_DEPTH_SORT_ONESWEEP_MIN 262144
 
 hipError_t depth_sort_temp_bytes(int P, size_t *bytes) {
+    const int dev = current_device();
+    {
+        std::lock_guard<std::mutex> lk(g_tsc.mu);
+        TempSizeCache::E *x = g_tsc.find(dev, P);
+        if (x && x->has_dsort) { *bytes = x->dsort; return hipSuccess; }
+    }
     size_t tb = 0, tb2 = 0;
     hipError_t e2 = rocprim::radix_sort_pairs(nullptr, tb2, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                               rocprim::counting_iterator<uint32_t>(0), (uint32_t *)nullptr,
@@ -62,6 +102,11 @@ hipError_t depth_sort_temp_bytes(int P, size_t *bytes) {
                                              rocprim::counting_iterator<uint32_t>(0), (uint32_t *)nullptr,
                                              (size_t)(P > 0 ? P : 1), 0u, 32u, (hipStream_t)0, false);
     *bytes = tb > tb2 ? tb : tb2;
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_tsc.mu);
+        TempSizeCache::E *x = g_tsc.slot(dev, P);
+        x->dsort = *bytes; x->has_dsort = true;
+    }
     return e;
 }
 

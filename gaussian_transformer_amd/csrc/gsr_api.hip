@@ -89,8 +89,10 @@ static DeviceState &dev_state() {
     return g_dev[d % GSR_MAX_DEVICES];
 }
 static const char *const k_stage_names[GSR_NUM_STAGES] = {
-    "fwd.preprocess", "fwd.depth_order+scan", "fwd.readback_N", "fwd.emit_keys", "fwd.sort", "fwd.ranges", "(unused)",
-    "fwd.composite", "bwd.zero_acc", "bwd.composite", "bwd.pergauss", "fwd.total", "bwd.total"};
+    // lists.bin = entries binned per super-tile (count + scan + scatter; round 1's path: depth order + scan); lists.order = per-super-tile order +
+    // expansion into the tile lists (sort path: the radix sort); emit_keys / ranges only run on the sort path
+    "fwd.preprocess", "fwd.lists.bin", "fwd.readback_N", "fwd.lists.emit_keys", "fwd.lists.order", "fwd.lists.ranges", "(unused)",
+    "fwd.composite", "bwd.clear+plan", "bwd.composite", "bwd.pergauss", "fwd.total", "bwd.total"};
 
 static int fail(int code, const char *fmt, ...) {
     va_list ap;

@@ -95,14 +95,15 @@ class GradientExchange:
       * active SH -- while the active SH degree D is below the stored one (train.py:72-73 raises it every 1000 iterations)
                      only the first (D+1)^2 coefficient columns of dL/dshs can be non-zero; `sh_active` exchanges just those
                      (3 instead of 48 floats per Gaussian at degree 0).
-      * sparse    -- `launch(visible=radii > 0)`: a Gaussian outside every camera's frustum has an all-zero gradient row.
-                     The ranks first agree on the union of their visibility masks (one MAX all-reduce of P bytes), compact the
-                     rows of that union, exchange the compacted buffer and scatter the sums back (rows outside the union stay
-                     zero).  With algo="direct" the sums are bitwise those of the dense exchange (see direct_all_reduce).
+      * sparse    -- `launch(visible=mask)`: a Gaussian no camera composited has an all-zero gradient row.  The ranks first agree on
+                     the union of their masks (one MAX all-reduce of P bytes), compact the rows of that union into a buffer of fixed
+                     capacity (no host synchronisation: the union's size is read when the exchange is waited for), exchange it and
+                     scatter the sums back (rows outside the union stay zero).  With algo="direct" the sums are bitwise those of
+                     the dense exchange (see direct_all_reduce).  The very first sparse exchange is as large as the dense one.
     bytes_last: payload bytes this rank handed to the collective(s) in the last launch()."""
 
     def __init__(self, P: int, M: int, device, has_scale_rot: bool = True, mode: str = "overlap", algo: str = "allreduce",
-                 bucket_bytes: int = 64 << 20, n_buffers: int = 2, group=None):
+                 bucket_bytes: int = 64 << 20, n_buffers: int = 2, group=None, sparse_slack=(1.25, 1024)):
         assert mode in ("sync", "overlap") and algo in ("allreduce", "direct")
         self.P, self.M, self.mode, self.algo, self.group = int(P), int(M), mode, algo, group
         self.device = torch.device(device)
@@ -118,6 +119,12 @@ class GradientExchange:
         self.scratch = None
         self.bytes_last = 0
         self.sh_active = None                            # None = all M coefficient columns
+        self.sparse_slack = sparse_slack                 # capacity of the compacted buffer = last union * [0] + [1] rows
+        self._union_known = None                         # size of the last union the sparse exchange looked at (None: never)
+        self._count_host = None
+        self._comp = None
+        self.union_rows = 0
+        self.sparse_overflows = 0
 
     # ---- buffers ----
     def arena(self) -> torch.Tensor:
@@ -197,25 +204,67 @@ class GradientExchange:
     def _pieces_of(self, t):
         return [t[lo:lo + self.bucket_floats] for lo in range(0, t.numel(), self.bucket_floats)]
 
+    # rows the compacted buffer of the sparse exchange holds: the union of the last step that was looked at, plus a quarter
+    def _sparse_capacity(self) -> int:
+        if self._union_known is None:
+            return self.P
+        return min(self.P, int(self._union_known * self.sparse_slack[0]) + int(self.sparse_slack[1]))
+
     def _launch_sparse(self, flat, visible, waits):
-        vis = visible.to(torch.uint8).contiguous()
+        """Exchange only the rows of the union of the ranks' masks, WITHOUT a host synchronisation on the compute stream: the rows are
+        compacted into a buffer of fixed capacity (what the union needed recently, + 25 %) through a prefix sum of the mask; the union's
+        size goes to the host asynchronously and is looked at when the exchange is waited for -- a union that did not fit (the camera
+        moved a lot) is exchanged densely then, from the gradients that are still untouched in the arena."""
+        vis = visible.to(torch.uint8, copy=True).contiguous()          # a copy: the reduction below must not overwrite the caller's mask
         self.bytes_last += vis.numel()
         dist.all_reduce(vis, op=dist.ReduceOp.MAX, group=self.group)      # union of the ranks' visibility masks
-        idx = torch.nonzero(vis, as_tuple=False).squeeze(1)
+        pos = torch.cumsum(vis, 0, dtype=torch.int64) - 1
+        cap = self._sparse_capacity()
+        count_dev = pos[-1:] + 1
+        if self.device.type == "cuda":
+            if self._count_host is None:
+                self._count_host = torch.zeros((1,), dtype=torch.int64).pin_memory()
+            self._count_host.copy_(count_dev, non_blocking=True)
+            count_ev = torch.cuda.Event(); count_ev.record(torch.cuda.current_stream(self.device))
+        else:
+            self._count_host, count_ev = count_dev.clone(), None
+        inside = (vis != 0) & (pos < cap)
+        idx = torch.where(inside, pos, torch.full_like(pos, cap))         # everything else lands in the dump row `cap`
         v = self.views(flat)
-        rows = torch.cat([v[n].reshape(self.P, -1) for n in self.names], dim=1)     # [P, 59] view-copy of the arena
-        comp = rows.index_select(0, idx).contiguous()                               # [n_union, 59]
-        for piece in self._pieces_of(comp.view(-1)):
+        widths = [v[n].reshape(self.P, -1).shape[1] for n in self.names]
+        W = sum(widths)
+        if self._comp is None or self._comp.shape[0] < cap + 1 or self._comp.shape[1] != W:
+            self._comp = torch.empty((cap + 1, W), dtype=flat.dtype, device=flat.device)
+        comp = self._comp[:cap + 1]
+        off = 0
+        for n, w in zip(self.names, widths):                              # gathered per parameter straight into the compacted buffer
+            comp[:, off:off + w].index_copy_(0, idx, v[n].reshape(self.P, w))
+            off += w
+        comp[cap].zero_()
+        payload = comp[:cap]
+        for piece in self._pieces_of(payload.reshape(-1)):
             self._reduce(piece, waits)
 
-        def scatter():
-            off = 0
-            for n in self.names:
-                w = v[n].reshape(self.P, -1).shape[1]       # rows outside the union are zero on every rank already
-                v[n].reshape(self.P, -1).index_copy_(0, idx, comp[:, off:off + w])
-                off += w
-        waits.append(_Deferred(scatter))
-        self.union_rows = int(idx.numel())
+        def finish():
+            if count_ev is not None:
+                count_ev.synchronize()                                    # recorded before the exchange was even launched: long done
+            n_union = int(self._count_host.item())
+            self._union_known = n_union
+            self.union_rows = n_union
+            if n_union > cap:                                             # did not fit: the arena still holds this rank's own gradients
+                self.sparse_overflows += 1
+                late: list = []
+                for piece in self._pieces(flat):
+                    self._reduce(piece, late)                             # same algorithm (and summation order) as the dense exchange
+                for w in late:
+                    w.wait()
+                return
+            comp[cap].zero_()
+            off2 = 0
+            for n, w in zip(self.names, widths):                          # rows outside the union are zero on every rank: the dump row
+                v[n].reshape(self.P, w).copy_(comp.index_select(0, idx)[:, off2:off2 + w])
+                off2 += w
+        waits.append(_Deferred(finish))
 
     def _wait_index(self, idx: int) -> None:
         waits = self.pending[idx]

@@ -8,5 +8,5 @@ for combo in "$@"; do
   timeout -k 10 200 python3 bench.py --config $cfg --steps 20 --warmup 3 --no-cpu-baseline $args 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); s=d['roofline']['stages']
-print('$cfg [$combo]', d['ms_per_step'], 'fwd.comp', s['fwd.composite']['ms'], 'bwd.zero', s['bwd.zero_acc']['ms'], 'bwd.comp', s['bwd.composite']['ms'], 'bwd.pg', s['bwd.pergauss']['ms'])" >> $out || exit 1
+print('$cfg [$combo]', d['ms_per_step'], 'fwd.comp', s['fwd.composite']['ms'], 'bwd.zero', s['bwd.clear+plan']['ms'], 'bwd.comp', s['bwd.composite']['ms'], 'bwd.pg', s['bwd.pergauss']['ms'])" >> $out || exit 1
 done

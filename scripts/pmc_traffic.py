@@ -7,13 +7,13 @@ figure is an upper bound for them.)   usage: pmc_traffic.py <pmc dir> <tag> <out
 import csv, glob, json, os, re, sys, collections
 
 d, tag, out = sys.argv[1], sys.argv[2], sys.argv[3]
-STAGES = [("composite_bwd_kernel", "bwd.composite"), ("composite_fwd_kernel", "fwd.composite"),
+STAGES = [("composite_bwd_kernel", "bwd.composite"), ("composite_bwd_pk_kernel", "bwd.composite"), ("zero_marked_rows_kernel", "bwd.clear+plan"), ("composite_fwd_kernel", "fwd.composite"),
           ("preprocess_fwd_kernel", "fwd.preprocess"), ("pergauss_bwd_kernel", "bwd.pergauss"),
-          ("ss_sort_expand_kernel", "fwd.sort"), ("ss_count_kernel", "fwd.depth_order+scan"), ("ss_scan_kernel", "fwd.depth_order+scan"),
-          ("ss_scatter_kernel", "fwd.depth_order+scan"),
-          ("do_hist_kernel", "fwd.depth_order+scan"), ("do_bucket_scan_kernel", "fwd.depth_order+scan"), ("do_scatter_kernel", "fwd.depth_order+scan"),
-          ("do_local_sort_kernel", "fwd.depth_order+scan"), ("tl_", "fwd.sort"),
-          ("emit_keys_kernel", "fwd.emit_keys"), ("tile_ranges", "fwd.ranges"), ("scan", "fwd.depth_order+scan"), ("onesweep", "fwd.sort"), ("histogram", "fwd.sort"), ("radix_sort", "fwd.sort"), ("rocprim", "fwd.sort")]
+          ("ss_sort_expand_kernel", "fwd.lists.order"), ("ss_count_kernel", "fwd.lists.bin"), ("ss_scan_kernel", "fwd.lists.bin"),
+          ("ss_scatter_kernel", "fwd.lists.bin"),
+          ("do_hist_kernel", "fwd.lists.bin"), ("do_bucket_scan_kernel", "fwd.lists.bin"), ("do_scatter_kernel", "fwd.lists.bin"),
+          ("do_local_sort_kernel", "fwd.lists.bin"), ("tl_", "fwd.lists.order"),
+          ("emit_keys_kernel", "fwd.lists.emit_keys"), ("tile_ranges", "fwd.lists.ranges"), ("scan", "fwd.lists.bin"), ("onesweep", "fwd.lists.order"), ("histogram", "fwd.lists.order"), ("radix_sort", "fwd.lists.order"), ("rocprim", "fwd.lists.order")]
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 
 

@@ -4,7 +4,7 @@
 set -u
 cfg=${1:-cfg2_table_300k_800}
 port=29511
-for mode in "GSR_EXCHANGE=overlap" "GSR_EXCHANGE=sync" "GSR_EXCHANGE=overlap GSR_ALLREDUCE=direct" "GSR_EXCHANGE=sync GSR_SPARSE=1 GSR_ALLREDUCE=direct" "GSR_EXCHANGE=overlap GSR_SPARSE=1"; do
+for mode in "GSR_X=default" "GSR_ALLREDUCE=direct" "GSR_SPARSE=1 GSR_ALLREDUCE=direct" "GSR_SPARSE=1" "GSR_EXCHANGE=overlap"; do
   port=$((port+1))
   echo "== $mode"
   env $mode GSR_DIST_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $port \

@@ -206,9 +206,18 @@ def _worker_exchange(rank, world, port, q):
             _fill(ex, g_c, P, M); a = ex.arenas[0]; ex.launch()
             out[algo, "sync_cam2"] = _read(ex, a, P)
             # sparse: union of the visibility masks, compacted rows
-            ex = GradientExchange(P, M, "cpu", mode="sync", algo=algo, bucket_bytes=4096)
-            _fill(ex, g, P, M); a = ex.arenas[0]; ex.launch(visible=torch.from_numpy(vis))
+            # (the first sparse exchange does not know the union's size yet and is as large as the dense one; the second is compact;
+            #  a union that outgrew the capacity is exchanged densely when it is waited for)
+            ex = GradientExchange(P, M, "cpu", mode="sync", algo=algo, bucket_bytes=4096, sparse_slack=(1.0, 0))
+            mask = torch.from_numpy(vis)
+            _fill(ex, g, P, M); a = ex.arenas[0]; ex.launch(visible=mask)
+            out[algo, "sparse_first"] = _read(ex, a, P); out[algo, "sparse_first_bytes"] = ex.bytes_last
+            assert bool((mask == torch.from_numpy(vis)).all())            # the caller's mask is not overwritten by the union
+            _fill(ex, g, P, M); ex.launch(visible=mask)
             out[algo, "sparse"] = _read(ex, a, P); out[algo, "sparse_bytes"] = ex.bytes_last; out[algo, "union"] = ex.union_rows
+            ex._union_known = 5                                            # far too small: overflow -> dense fall-back at wait time
+            _fill(ex, g, P, M); ex.launch(visible=mask)
+            out[algo, "sparse_overflow"] = _read(ex, a, P); out[algo, "overflows"] = ex.sparse_overflows
             # active SH degree 0 of M = 4: the other coefficient columns are zero on every rank
             g0 = g.copy(); g0.reshape(P, -1)[:, 3 + 3:3 + 3 * M] = 0.0
             ex = GradientExchange(P, M, "cpu", mode="sync", algo=algo); _fill(ex, g0, P, M); a = ex.arenas[0]; ex.launch()
@@ -256,4 +265,8 @@ def test_gradient_exchange_variants_equal_the_dense_sum(world):
             assert o[algo, "sh_bytes"][0] == o[algo, "sh_bytes"][1] - 4 * P * 3 * (M - 1)
             same(o[algo, "sparse"], o[algo, "dense"])    # bitwise with rank-order sums (direct) or two ranks; a ring of three
                                                          # differs in the last bit only (buffer position decides the order)
+            same(o[algo, "sparse_first"], o[algo, "dense"])
+            assert o[algo, "sparse_first_bytes"] == P + 4 * P * (3 + 3 * M + 8)
+            same(o[algo, "sparse_overflow"], o[algo, "dense"])
+            assert o[algo, "overflows"] == 1
         np.testing.assert_array_equal(res[0]["direct", "dense"], serial)                      # direct = the serial rank-order sum, bitwise
