@@ -409,6 +409,10 @@ def main():
         cpu["rgb_max_abs_diff_vs_gpu"] = img["max_diff"]
         cpu["rgb_frac_pixels_over_1e-4"] = img["frac_over"]
         cpu["rgb_pixels_over_1e-4_without_borderline_decision"] = img["uncertified"]
+        from tests.helpers import certify_image_constructive
+        ic = certify_image_constructive(state["color"].detach().cpu().numpy(), f)
+        cpu["rgb_pixels_over_1e-4_reproduced_by_reversing_a_decision"] = ic["certified"]
+        cpu["rgb_pixels_over_1e-4_unexplained"] = len(ic["unexplained"]) + ic["not_examined"]
         hip_g = dict(zip(("means3D", "opacities", "shs", "scales", "rotations"), (x.detach().cpu().numpy() for x in state["grads"])))
         gd = {}
         for hk, rk in GRAD_KEYS:

@@ -59,6 +59,7 @@ SIGNATURES = {
     "gsr_debug_read_lane_counters": (_i32, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gsr_debug_read_wave_trace": (_i32, [_i32, _p, C.c_int64]),
     "gsr_debug_read_segments": (_i32, [_p, _i32, _i32, _p, _p]),
+    "gsr_debug_read_bound_errors": (_i32, [_p, _i32, _p, _i32, _i32, _p, _p]),
     "gsr_l1_ssim_workspace": (_i32, [_i32, _i32, _i32, C.POINTER(_sz)]),
     "gsr_l1_ssim_forward": (_i32, [_p, _i32, _i32, _i32, _p, _p, _f, _p, _p, _sz]),
     "gsr_l1_ssim_backward": (_i32, [_p, _i32, _i32, _i32, _p, _p, _f, _p, _p, _sz, _p]),

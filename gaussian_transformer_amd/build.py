@@ -57,23 +57,37 @@ def _newer(src_list, target) -> bool:
     return any(os.path.getmtime(s) > t for s in src_list)
 
 
-def build_variant(tag: str, defines, verbose: bool = False) -> str:
-    """Ablation build: every TU recompiled with extra -D flags into libgsr_hip_<tag>.so (scratch use)."""
+def build_variant(tag: str, defines, verbose: bool = False, force: bool = False) -> str:
+    """Variant build: every TU recompiled with extra -D flags into libgsr_hip_<tag>.so (ablations; "dbg" = the capacity-assert build,
+    -DGSR_DEBUG_BOUNDS, csrc/gsr_internal.h).  Loaded instead of the product library through GSR_LIB_PATH."""
     cc = hipcc()
     out = os.path.join(HERE, f"libgsr_hip_{tag}.so")
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    objs = []
     odir = os.path.join(OBJ, tag)
     os.makedirs(odir, exist_ok=True)
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [os.path.abspath(__file__)]
+    headers += [os.path.join(HERE, "..", "include", h) for h in ("gsr.h", "gsr_loss.h", "gsr_knn.h", "gsr_optim.h")]
+    jobs, objs = [], []
     for src, extra in SOURCES.items():
-        o = os.path.join(odir, src.replace(".hip", ".o"))
-        cmd = [cc, "-c", os.path.join(CSRC, src), "-o", o] + COMMON + extra + [f"-D{d}" for d in defines]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        s, o = os.path.join(CSRC, src), os.path.join(odir, src.replace(".hip", ".o"))
         objs.append(o)
-    subprocess.check_call([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs)
+        if force or _newer([s] + headers, o):
+            jobs.append([cc, "-c", s, "-o", o] + COMMON + extra + [f"-D{d}" for d in defines])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _newer(objs, out):
+        subprocess.check_call([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs)
     return out
+
+
+def build_debug_bounds(force: bool = False, verbose: bool = False) -> str:
+    return build_variant("dbg", ["GSR_DEBUG_BOUNDS"], verbose=verbose, force=force)
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
@@ -118,3 +132,5 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build_hip(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))
+    if "--debug-bounds" in sys.argv:
+        print(build_debug_bounds(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))

@@ -144,7 +144,7 @@ __device__ __forceinline__ void bwd_unit(const CompositeBwdArgs &a, float4 *my, 
         const int cnt = min(64, hi - base);
         __builtin_amdgcn_wave_barrier();
         bool live = false;
-        if (lane < cnt) {
+        if (lane < cnt && GSR_IDX_OK((size_t)range.x + base + lane, a.contrib_stride, a.seg.hdr + GSR_DBG_SEG_WORD, GSR_BOUND_BWD_LIST_READ)) {
             const uint32_t g = a.point_list[range.x + base + lane];
             const float4 r0 = rec4[3 * (size_t)g], r1 = rec4[3 * (size_t)g + 1], r2 = rec4[3 * (size_t)g + 2];
             // blocks this entry can reach (exact ellipse-vs-block test, gsr_device.h), as the forward pass staged them
@@ -391,6 +391,7 @@ __global__ __launch_bounds__(64) void composite_bwd_pk_kernel(CompositeBwdArgs a
         }
         const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
         const size_t at = seg_list_base(a.seg, band) + ticket;
+        if (!GSR_IDX_OK(ticket, a.seg.list_cap, hdr + GSR_DBG_SEG_WORD, GSR_BOUND_UNIT_TICKET)) break;
         uint4 u = a.seg.bq[at];
         u.x = __builtin_amdgcn_readfirstlane(u.x); u.y = __builtin_amdgcn_readfirstlane(u.y);
         u.z = __builtin_amdgcn_readfirstlane(u.z); u.w = __builtin_amdgcn_readfirstlane(u.w);
@@ -483,7 +484,7 @@ __device__ void plan_units(const SegView &v, const int band, const int fillP, co
             const uint32_t slots[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
 #pragma unroll
             for (uint32_t k = 0; k < GSR_SEG_MAXCK; k++)
-                if (k < kt) list[p + k] = make_uint4(u, k * seg, (k + 1u) * seg, slots[k]);
+                if (k < kt && GSR_IDX_OK(p + k, v.list_cap, v.hdr + GSR_DBG_SEG_WORD, GSR_BOUND_UNIT_LIST)) list[p + k] = make_uint4(u, k * seg, (k + 1u) * seg, slots[k]);
         }
         unsigned long long todo = __ballot(ml != 0u);
         while (todo) {
@@ -493,7 +494,10 @@ __device__ void plan_units(const SegView &v, const int band, const int fillP, co
             uint32_t cbase = 0u;
             if (lane == leader) cbase = atomicAdd(&cur[c], (uint32_t)__builtin_popcountll(same));
             cbase = __shfl(cbase, leader);
-            if (ml != 0u && cls == c) list[hist[c] + cbase + (uint32_t)__builtin_popcountll(same & below)] = make_uint4(u, kt * seg, ml, ~0u);
+            if (ml != 0u && cls == c) {
+                const uint32_t at = hist[c] + cbase + (uint32_t)__builtin_popcountll(same & below);
+                if (GSR_IDX_OK(at, v.list_cap, v.hdr + GSR_DBG_SEG_WORD, GSR_BOUND_UNIT_LIST)) list[at] = make_uint4(u, kt * seg, ml, ~0u);
+            }
             todo &= ~same;
         }
     };
@@ -653,6 +657,15 @@ hipError_t launch_composite_bwd_persistent(const CompositeBwdArgs &a, int grid, 
         hipLaunchKernelGGL((composite_bwd_pk_kernel<1, false>), dim3(grid), dim3(64), lds, s, a);
     else
         hipLaunchKernelGGL((composite_bwd_pk_kernel<0, false>), dim3(grid), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+
+// debug-build self test: one deliberate out-of-range index; the words must then read (GSR_BOUND_SELFTEST, 5, 4, 1)
+__global__ void bound_selftest_kernel(uint32_t *words) {
+    if (GSR_IDX_OK(5, 4, words, GSR_BOUND_SELFTEST)) words[0] = 0xdeadu;
+}
+hipError_t launch_bound_selftest(uint32_t *words, hipStream_t s) {
+    hipLaunchKernelGGL(bound_selftest_kernel, dim3(1), dim3(1), 0, s, words);
     return hipGetLastError();
 }
 

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
                 slot = __builtin_amdgcn_readfirstlane(slot);
                 if (slot < share) {                   // else: the share is used up, this half tile stays one unit from here on
                     slot += band * share;
+                    if (!GSR_IDX_OK(slot, a.seg.pool_cap, a.seg.hdr + GSR_DBG_SEG_WORD, GSR_BOUND_POOL_SLOT)) slot = 0u;
                     float4 *ck = a.seg.pool + (size_t)slot * 128 + lane;
 #pragma unroll
                     for (int q = 0; q < NPX; q++) {
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
         }
         __builtin_amdgcn_wave_barrier();
         bool live = false;
-        if (lane < cnt) {
+        if (lane < cnt && GSR_IDX_OK((size_t)range.x + base + lane, a.contrib_stride, a.seg.hdr + GSR_DBG_SEG_WORD, GSR_BOUND_FWD_LIST_READ)) {
             const uint32_t g = a.point_list[range.x + base + lane];
             float4 r0 = rec4[3 * (size_t)g], r1 = rec4[3 * (size_t)g + 1];
             const float4 r2 = rec4[3 * (size_t)g + 2];

@@ -910,6 +910,35 @@ int32_t gsr_debug_read_wave_trace(int32_t which, uint32_t *out, int64_t max_unit
     return GSR_OK;
 }
 
+int32_t gsr_debug_read_bound_errors(gsr_stream_t stream, int32_t P, const void *geom_ws, int32_t W, int32_t H, const void *img_ws, uint32_t *out) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!out) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_debug_read_bound_errors: bad argument");
+    memset(out, 0, 12 * sizeof(uint32_t));
+#ifdef GSR_DEBUG_BOUNDS
+    out[8] = 1u;
+#endif
+    HIP_TRY(hipStreamSynchronize(s), "sync");
+    if (geom_ws && P > 0) {
+        size_t stb = 0, dtb = 0;
+        HIP_TRY(scan_temp_bytes(P, &stb), "scan temp query");
+        HIP_TRY(depth_sort_temp_bytes(P, &dtb), "depth sort temp query");
+        const GeomView g = carve_geom(const_cast<void *>(geom_ws), P, stb, dtb);
+        HIP_TRY(hipMemcpy(out, g.dord.hdr + GSR_DBG_GEOM_WORD, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost), "copy bound words");
+    }
+    if (img_ws && W > 0 && H > 0) {
+        const ImageView im = carve_image(const_cast<void *>(img_ws), W, H);
+        HIP_TRY(hipMemcpy(out + 4, im.seg.hdr + GSR_DBG_SEG_WORD, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost), "copy bound words");
+        // self test of the mechanism, on words of its own (seg.hdr[8..11])
+        HIP_TRY(hipMemsetAsync(im.seg.hdr + 8, 0, 4 * sizeof(uint32_t), s), "clear self-test words");
+        HIP_TRY(launch_bound_selftest(im.seg.hdr + 8, s), "bound self test");
+        HIP_TRY(hipStreamSynchronize(s), "sync");
+        uint32_t st[4];
+        HIP_TRY(hipMemcpy(st, im.seg.hdr + 8, sizeof(st), hipMemcpyDeviceToHost), "copy self-test words");
+        out[9] = st[0]; out[10] = st[1]; out[11] = st[2];
+    }
+    return GSR_OK;
+}
+
 int32_t gsr_debug_read_segments(gsr_stream_t stream, int32_t W, int32_t H, const void *img_ws, uint32_t *summary) {
     hipStream_t s = (hipStream_t)stream;
     if (!img_ws || !summary || W <= 0 || H <= 0) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_debug_read_segments: bad argument");

@@ -9,6 +9,29 @@
 
 namespace gsr {
 
+// ---- capacity asserts of the debug build (python -m gaussian_transformer_amd.build --debug-bounds -> libgsr_hip_dbg.so) ----
+// Every index into an LDS list, an entry run, a tile list, a unit list or the checkpoint pool whose bound is a PLAN made on the host
+// or in another kernel (GSR_SS_CAP, the entry capacity, N, the list capacities ...) goes through GSR_IDX_OK in that build: an index
+// at or beyond its capacity is recorded -- (code, index, capacity, count) in four spare words of the workspace headers, read by
+// gsr_debug_read_bound_errors -- and the access is skipped, so the process survives and the test can say which bound broke.
+// In the product build the macro is the constant `true` and costs nothing.
+#define GSR_DBG_GEOM_WORD 12    // dord.hdr[12..15] (zeroed by preprocess with the other counters)
+#define GSR_DBG_SEG_WORD 4      // seg.hdr[4..7]
+#ifdef GSR_DEBUG_BOUNDS
+__device__ __forceinline__ bool gsr_idx_ok(unsigned long long idx, unsigned long long cap, const uint32_t *words_c, uint32_t code) {
+    if (idx < cap) return true;
+    uint32_t *w = const_cast<uint32_t *>(words_c);
+    if (atomicAdd(&w[3], 1u) == 0u) { w[0] = code; w[1] = (uint32_t)idx; w[2] = (uint32_t)cap; }
+    return false;
+}
+#define GSR_IDX_OK(idx, cap, words, code) gsr_idx_ok((unsigned long long)(idx), (unsigned long long)(cap), (words), (code))
+#else
+#define GSR_IDX_OK(idx, cap, words, code) true
+#endif
+enum { GSR_BOUND_SS_BIG_LIST = 1, GSR_BOUND_SS_ENTRIES = 2, GSR_BOUND_SS_BIN_SIZE = 3, GSR_BOUND_SS_LDS_POS = 4, GSR_BOUND_POINT_LIST = 5,
+       GSR_BOUND_FWD_LIST_READ = 6, GSR_BOUND_POOL_SLOT = 7, GSR_BOUND_BWD_LIST_READ = 8, GSR_BOUND_UNIT_LIST = 9, GSR_BOUND_UNIT_TICKET = 10,
+       GSR_BOUND_SELFTEST = 99 };
+
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline int ceil_log2_u32(uint32_t x) { int b = 0; while ((1u << b) < x && b < 31) b++; return b; }
 
@@ -319,6 +342,7 @@ struct CompositeBwdArgs {
     FillArgs fill;           // persistent kernel only
 };
 hipError_t launch_composite_bwd(const CompositeBwdArgs &a, int npx, int exact_cull, int waves_per_block, hipStream_t s);
+hipError_t launch_bound_selftest(uint32_t *words, hipStream_t s);
 // persistent reverse kernel (2 blocks per wave): `grid` waves draw the units the forward pass filed; the ticket counter must hold `grid`
 hipError_t launch_composite_bwd_persistent(const CompositeBwdArgs &a, int grid, hipStream_t s);
 int composite_bwd_persistent_grid(int T, int det, int count_mode);

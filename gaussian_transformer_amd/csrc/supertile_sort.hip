@@ -167,7 +167,11 @@ __device__ __forceinline__ void ss_for_chunk_entries(const SsBinArgs &a, const S
             const uint32_t kind = sr[k].y >> 29;
             if (!kind) continue;
             const int i = base + k * SS_BIN_THREADS + (int)threadIdx.x;
-            if (kind == 2u) { l.big[atomicAdd(l.nbig, 1u)] = (uint32_t)i; continue; }      // at most `chunk` of them
+            if (kind == 2u) {                                                               // at most `chunk` of them
+                const uint32_t at = atomicAdd(l.nbig, 1u);
+                if (GSR_IDX_OK(at, a.chunk + (SS_BIN_THREADS / 64) * 64, a.hdr + GSR_DBG_GEOM_WORD, GSR_BOUND_SS_BIG_LIST)) l.big[at] = (uint32_t)i;
+                continue;
+            }
             if (kind == 3u) {
                 const uint32_t slot = atomicAdd(l.nmid, 1u);
                 if (slot < GSR_SS_MIDCAP) { l.midrec[slot] = sr[k]; l.midid[slot] = (uint32_t)i; }
@@ -350,7 +354,8 @@ __global__ __launch_bounds__(SS_BIN_THREADS) void ss_scatter_kernel(SsBinArgs a)
     if (threadIdx.x == 0) { s_nbig = 0u; s_nmid = 0u; }
     __syncthreads();
     ss_for_chunk_entries<false>(a, l, [&](int bin, uint32_t m, uint32_t id, uint32_t d) {
-        a.entries[basep[bin] + atomicAdd(&rank[bin], 1u)] = make_uint4(d, id, m, 0u);
+        const uint32_t at = basep[bin] + atomicAdd(&rank[bin], 1u);
+        if (GSR_IDX_OK(at, (unsigned long long)GSR_SS_ENT_PER_G * a.P, a.hdr + GSR_DBG_GEOM_WORD, GSR_BOUND_SS_ENTRIES)) a.entries[at] = make_uint4(d, id, m, 0u);
         atomicAdd(&prs[bin], (uint32_t)__popc(m));
     });
     __syncthreads();
@@ -378,7 +383,8 @@ __global__ __launch_bounds__(SS_THREADS, CAP <= GSR_SS_CAP ? 8 : 4) void ss_sort
     if (a.hdr[DO_OVERFLOW]) return;                                // grid-uniform
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t e0 = a.bin_start[s];
-    const int n = (int)a.bin_cur[s];                               // entries actually written (empty masks were dropped)
+    int n = (int)a.bin_cur[s];                                     // entries actually written (empty masks were dropped)
+    if (!GSR_IDX_OK(n, CAP + 1, a.hdr + GSR_DBG_GEOM_WORD, GSR_BOUND_SS_BIN_SIZE)) n = CAP;      // debug build: a bin beyond the LDS buffer
     // pairs of the super-tiles before this one = where its region of point_list starts
     {
         uint32_t before = 0;
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(SS_THREADS, CAP <= GSR_SS_CAP ? 8 : 4) void ss_sort
         for (int q = 0; q < ITEMS; q++)
             if (tid + q * SS_THREADS < n) {
                 const uint32_t pos = atomicAdd(&cur[sub_of(key[q])], 1u);      // arrival order inside the sub-bucket is irrelevant
-                buf[pos] = key[q]; mbuf[pos] = (uint16_t)msk[q];
+                if (GSR_IDX_OK(pos, CAP, a.hdr + GSR_DBG_GEOM_WORD, GSR_BOUND_SS_LDS_POS)) { buf[pos] = key[q]; mbuf[pos] = (uint16_t)msk[q]; }
             }
         __syncthreads();
     }
@@ -562,7 +568,7 @@ __global__ __launch_bounds__(SS_THREADS, CAP <= GSR_SS_CAP ? 8 : 4) void ss_sort
 #pragma unroll
         for (int t = 0; t < 16; t++) {
             const uint32_t bitv = (m[q] >> t) & 1u;
-            if (bitv) a.point_list[pos[t]] = idv[q];
+            if (bitv && GSR_IDX_OK(pos[t], a.hdr[SS_HDR_N], a.hdr + GSR_DBG_GEOM_WORD, GSR_BOUND_POINT_LIST)) a.point_list[pos[t]] = idv[q];
             pos[t] += bitv;
         }
     }

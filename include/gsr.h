@@ -143,6 +143,14 @@ int32_t gsr_debug_read_binning(gsr_stream_t stream, int64_t N, int32_t W, int32_
 int32_t gsr_debug_read_image_state(gsr_stream_t stream, int32_t W, int32_t H, const void *img_ws,
                                    float *final_T /*[H,W]*/, uint32_t *n_contrib /*[H,W]*/);
 
+/* Capacity asserts of the debug build (libgsr_hip_dbg.so, compiled with -DGSR_DEBUG_BOUNDS: every index whose bound is a plan made on the
+ * host or by another kernel is checked on the device; a violation is recorded and the access skipped instead of faulting).
+ * out[0..3] = first violation in the list-building kernels (code, index, capacity, number of violations), out[4..7] = the same for the
+ * compositing / planning kernels, out[8] = 1 in a debug build, out[9..11] = the mechanism's self test: (99, 5, 4) in a debug build,
+ * (0xdead, 0, 0) in the product build, where the checks are compiled out.  Synchronises. */
+int32_t gsr_debug_read_bound_errors(gsr_stream_t stream, int32_t P, const void *geom_ws, int32_t W, int32_t H, const void *img_ws,
+                                    uint32_t *out /*[12] host*/);
+
 /* What the forward pass left for the segmented reverse pass and what the last gsr_backward made of it (tests): summary[0] = entries
  * per segment the forward pass used (0: none), [1] = work units of the last gsr_backward's lists, [2] = checkpoint slots handed
  * out, [3] = slots in the pool, [4] = half tiles, [5] = tickets drawn by the last persistent reverse kernel.  Synchronises. */

@@ -102,6 +102,109 @@ def assert_image_certified(hip_color, ref_color, margin, atol=RGB_ATOL):
     return st
 
 
+# ---------------------------------------------------------------------------------------------
+# Constructive certificate: a pixel over 1e-4 is accepted only if re-compositing THAT pixel in float32 with one or
+# two of the oracle's borderline decisions taken the other way reproduces the HIP value to 1e-4 -- a demonstration, not a margin
+# ---------------------------------------------------------------------------------------------
+ALPHA_MIN32, ALPHA_MAX32, T_MIN32 = np.float32(1.0 / 255.0), np.float32(0.99), np.float32(1e-4)
+BORDERLINE = 1e-3          # decisions within this (relative; absolute for the sign of power) of their threshold are candidates for a flip
+MAX_CERTIFIED_FRAC = 1e-5  # of the image's pixels (at least 3 pixels)
+
+
+def recomposite_pixel(geom, vals, r0, r1, x, y, bg, flips=()):
+    """One pixel of S9 in float32, exactly as oracle/gsr_ref.c walks it (same operation order), with the decisions named in
+    `flips` -- (list position, 'power' | 'alpha' | 'T') -- taken the other way.  Returns (rgb[3], decisions) where decisions lists
+    (position, kind, margin) of every decision taken, margin as gsr_ref.c defines it."""
+    f32 = np.float32
+    xy, co, rgb = geom["xy"], geom["conic_o"], geom["rgb"]
+    Tr = f32(1.0); C = np.zeros(3, np.float32)
+    decisions = []
+    flips = set(flips)
+    for pos, j in enumerate(range(int(r0), int(r1))):
+        g = int(vals[j])
+        dx = f32(xy[g, 0] - f32(x)); dy = f32(xy[g, 1] - f32(y))
+        power = f32(f32(-0.5) * f32(f32(co[g, 0] * dx * dx) + f32(co[g, 2] * dy * dy)) - f32(f32(co[g, 1] * dx) * dy))
+        araw = f32(co[g, 3] * np.exp(power, dtype=np.float32))
+        skip = bool(power > 0)
+        if araw >= ALPHA_MIN32 * f32(0.5):
+            decisions.append((pos, "power", abs(float(power))))
+        if (pos, "power") in flips:
+            skip = not skip
+        if skip:
+            continue
+        alpha = min(araw, ALPHA_MAX32)
+        decisions.append((pos, "alpha", abs(float((alpha - ALPHA_MIN32) / ALPHA_MIN32))))
+        skip = bool(alpha < ALPHA_MIN32)
+        if (pos, "alpha") in flips:
+            skip = not skip
+        if skip:
+            continue
+        Tn = f32(Tr * f32(f32(1.0) - alpha))
+        decisions.append((pos, "T", abs(float((Tn - T_MIN32) / T_MIN32))))
+        stop = bool(Tn < T_MIN32)
+        if (pos, "T") in flips:
+            stop = not stop
+        if stop:
+            break
+        w = f32(alpha * Tr)
+        C = (C + rgb[g].astype(np.float32) * w).astype(np.float32)
+        Tr = Tn
+    return (C + Tr * np.asarray(bg, np.float32)).astype(np.float32), decisions
+
+
+def certify_image_constructive(hip_color, f32_fwd, atol=RGB_ATOL, max_pixels=400):
+    """Every pixel over `atol`: find one or two borderline decisions whose reversal makes the float32 re-composite agree with the HIP
+    pixel to `atol`.  Returns statistics; `unexplained` lists the pixels for which no such reversal exists."""
+    ref_color = np.asarray(f32_fwd["color"])
+    d = np.abs(np.asarray(hip_color, np.float64) - ref_color.astype(np.float64)).max(axis=0)
+    H, W = d.shape
+    ys, xs = np.nonzero(d > atol)
+    st = f32_fwd["state"]
+    out = dict(pixels=int(d.size), over=int(len(ys)), frac_over=float(len(ys) / d.size), max_diff=float(d.max()), certified=0, unexplained=[],
+               not_examined=max(0, len(ys) - max_pixels))
+    if len(ys) == 0:
+        return out
+    geom, binn = st.geom(), st.binning()
+    gridx = (W + 15) // 16
+    bg = np.asarray(st.sc.bg, np.float32)
+    for y, x in list(zip(ys, xs))[:max_pixels]:
+        t = (y // 16) * gridx + (x // 16)
+        r0, r1 = binn["ranges"][t]
+        target = np.asarray(hip_color)[:, y, x].astype(np.float64)
+        base, dec = recomposite_pixel(geom, binn["vals"], r0, r1, x, y, bg)
+        cand = sorted([(m, p, k) for p, k, m in dec if m < BORDERLINE])[:8]
+        found = None
+        if np.abs(base.astype(np.float64) - target).max() <= atol:
+            found = ()                                   # numpy's exp differs from the oracle's libm in the last bit at this very pixel
+        for i, (_, p, k) in enumerate(cand):
+            if found is not None:
+                break
+            c1, _ = recomposite_pixel(geom, binn["vals"], r0, r1, x, y, bg, flips=[(p, k)])
+            if np.abs(c1.astype(np.float64) - target).max() <= atol:
+                found = ((p, k),)
+        if found is None:
+            for i in range(len(cand)):
+                for j in range(i + 1, len(cand)):
+                    fl = [(cand[i][1], cand[i][2]), (cand[j][1], cand[j][2])]
+                    c2, _ = recomposite_pixel(geom, binn["vals"], r0, r1, x, y, bg, flips=fl)
+                    if np.abs(c2.astype(np.float64) - target).max() <= atol:
+                        found = tuple(fl); break
+                if found is not None:
+                    break
+        if found is None:
+            out["unexplained"].append(dict(x=int(x), y=int(y), diff=float(d[y, x]), borderline=[(int(p), k, float(m)) for m, p, k in cand]))
+        else:
+            out["certified"] += 1
+    return out
+
+
+def assert_image_constructive(hip_color, f32_fwd, atol=RGB_ATOL):
+    st = certify_image_constructive(hip_color, f32_fwd, atol)
+    assert not st["unexplained"] and st["not_examined"] == 0, f"pixels over {atol} that no reversed borderline decision explains: {st}"
+    assert st["over"] <= max(3, MAX_CERTIFIED_FRAC * st["pixels"]), f"too many pixels over {atol} (each explained by a reversed decision, but): {st}"
+    return st
+
+
 def grad_rows(a, b, rtol=GRAD_RTOL, floor_rel=1e-3):
     """Per-Gaussian gradient parity.  a, b: [P, ...] (HIP / float64 oracle).  For every Gaussian i
         e_i = max_c |a_ic - b_ic| / max(max_c |b_ic|, floor),   floor = floor_rel * median_i(max_c |b_ic| over non-zero rows)
@@ -155,7 +258,21 @@ def parity_report(S, dL, hip=None, nthreads=0):
     margin = f32["state"].decision_margin()
     f64 = r64.forward(S, nthreads=nt); g64 = r64.backward(f64, dL, nthreads=nt)
     h = hip if hip is not None else hip_forward_backward(S, dL)
+    # where the max-norm difference against the float32 oracle sits, and how far HIP and the float32 oracle each are from float64 THERE:
+    # a large max-norm figure at an element where the float32 oracle itself is as far from float64 is the oracle's rounding, not the kernels'
+    worst = {}
+    for hk, rk in GRAD_KEYS:
+        if h["grads"].get(hk) is None or g32.get(rk) is None:
+            continue
+        a = np.asarray(h["grads"][hk], np.float64); b = np.asarray(g32[rk], np.float64).reshape(a.shape); c = np.asarray(g64[rk], np.float64).reshape(a.shape)
+        if a.size == 0:
+            continue
+        i = int(np.abs(a - b).argmax()); scale = max(float(np.abs(b).max()), 1e-30)
+        worst[hk] = dict(flat_index=i, gaussian=int(i // max(1, a.size // a.shape[0])), hip=float(a.flat[i]), f32=float(b.flat[i]), f64=float(c.flat[i]),
+                         hip_vs_f64=float(abs(a.flat[i] - c.flat[i]) / scale), f32_vs_f64=float(abs(b.flat[i] - c.flat[i]) / scale),
+                         hip_vs_f32=float(abs(a.flat[i] - b.flat[i]) / scale))
     rep = dict(P=int(np.asarray(S.means3D).shape[0]), W=S.W, H=S.H, num_rendered_reference_rule=int(f32["num_rendered"]),
+               image_constructive=certify_image_constructive(h["color"], f32), grads_maxnorm_where=worst,
                radii_equal=bool(np.array_equal(h["radii"], f32["radii"])),
                radii_f32_vs_f64_differ=int((f32["radii"] != f64["radii"]).sum()),
                image=certify_image(h["color"], f32["color"], margin),
@@ -167,16 +284,29 @@ def parity_report(S, dL, hip=None, nthreads=0):
     return rep
 
 
+# gates on the HIP kernels against the float32 oracle directly (what they were observed to deliver in round 2: fail fraction <= 1.1e-3,
+# p99 <= 5e-5 on every BASELINE configuration), besides the "as close to float64 as a float32 evaluation" comparison
+F32_FAIL_FRAC_MAX = 2e-3
+F32_P99_MAX = 1e-4
+MAXNORM_NET = 2e-3
+
+
 def assert_parity(rep):
     assert rep["radii_equal"], "radii differ from the float32 oracle"
     im = rep["image"]
     assert im["uncertified"] == 0, f"pixels over {RGB_ATOL} without a borderline decision: {im}"
     assert im["max_diff"] <= FLIP_MAX, im
+    ic = rep["image_constructive"]
+    assert not ic["unexplained"] and ic["not_examined"] == 0, f"pixels over {RGB_ATOL} that no reversed borderline decision explains: {ic}"
+    assert ic["over"] <= max(3, MAX_CERTIFIED_FRAC * ic["pixels"]), ic
     for k, g in rep["grads"].items():
         base = rep["grads_f32_oracle"][k]
         assert g["fail_frac"] <= 2.0 * base["fail_frac"] + 1e-3, (k, g, base)
         assert g["p99"] <= max(GRAD_RTOL, 2.0 * base["p99"]), (k, g, base)
-        # against the float32 oracle directly (round 1's max-norm figure, kept as a coarse net: one flipped alpha test on
-        # the Gaussian with the largest gradient of a tensor moves it by ~1e-3)
-        assert rep["grads_maxnorm_vs_f32"][k] < 5 * GRAD_RTOL, (k, rep["grads_maxnorm_vs_f32"][k])
-        assert rep["grads_vs_f32"][k]["p99"] <= GRAD_RTOL, (k, rep["grads_vs_f32"][k])
+        v32 = rep["grads_vs_f32"][k]
+        assert v32["fail_frac"] <= F32_FAIL_FRAC_MAX, (k, v32)
+        assert v32["p99"] <= F32_P99_MAX, (k, v32)
+        # max-norm against the float32 oracle (round 1's figure) as a net -- unless, at the very element where it is largest, the HIP
+        # value is as close to float64 as the float32 oracle's is (then that element measures the oracle's rounding, not the kernels')
+        mn, w = rep["grads_maxnorm_vs_f32"][k], rep["grads_maxnorm_where"].get(k)
+        assert mn < MAXNORM_NET or (w is not None and w["hip_vs_f64"] <= 1.2 * w["f32_vs_f64"] + 1e-5), (k, mn, w)
