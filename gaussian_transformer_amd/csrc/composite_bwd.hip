@@ -178,12 +178,13 @@ __device__ __forceinline__ void bwd_unit(const CompositeBwdArgs &a, float4 *my, 
             const int pos = base + j;
             unsigned long long any_ok = 0ull;         // 64-bit lane mask kept in SGPRs
             const StagedConic kc = {r0.z, r0.w, r1.x};
-            const RowTerms rt = splat_row_terms(kc, r0.y - fy[0]);   // NPX == 2: both blocks lie in one row of the tile
+            const RowTerms rt = splat_row_terms(kc, r0.y - fy[0]);   // blocks side by side share dy (gsr_device.h); the forward pass forms the exponent the same way
+            const RowTerms rt1 = NPX == 4 ? splat_row_terms(kc, r0.y - fy[NPX - 1]) : rt;
             // body for one 8x8 block
             auto block_body = [&](int q) __attribute__((always_inline)) {
                 const float dx = r0.x - fx[q], dy = r0.y - fy[q];
                 float araw;                                          // same expression, same bits as the forward pass
-                const unsigned long long okm = splat_alpha(NPX == 2 ? splat_power_log2_row(kc, rt, dx) : splat_power_log2(kc, dx, dy), r1.y, araw) &
+                const unsigned long long okm = splat_alpha(splat_power_log2_row(kc, (NPX == 4 && q >= 2) ? rt1 : rt, dx), r1.y, araw) &
                                                __builtin_amdgcn_ballot_w64(pos < last[q]);
                 any_ok |= okm;
                 if (COUNT == 1) {

@@ -29,20 +29,16 @@ __device__ __forceinline__ int xcd_band_unit_f(int b, int nblocks_padded) {
 
 // COUNT: instrumented instantiations (gsr_set_option("count_lanes", 1 or 2)): 1 = lane-slot accounting (several times slower), see
 // CompositeCounters; 2 = wave timeline only (two clock reads and one store per wave: the kernel runs at its normal speed)
+// One work unit: the NPX blocks `sub` names of `tile`, the whole list.  `trace_id`: where the instrumented builds file the wave's timeline.
 template <int NPX, int COUNT>
-__global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int nblocks_padded, int exact_cull) {
+__device__ __forceinline__ void fwd_unit(const CompositeArgs &a, float4 *my, const int lane, const int tile, const int sub, const int trace_id,
+                                         const int exact_cull) {
     constexpr int UNITS_PER_TILE = 4 / NPX;
-    extern __shared__ __align__(16) float4 stage_dyn[];     // [waves per block][64 * 3]
-    const int T = a.gridx * a.gridy;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
-    const int unit = xcd_band_unit_f(blockIdx.x, nblocks_padded) * wpb + wave;
-    const int tile = unit / UNITS_PER_TILE, sub = unit % UNITS_PER_TILE;
-    if (tile >= T) return;                            // wave-uniform
+    const int unit = tile * UNITS_PER_TILE + sub;
     const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
     const int tx = tile % a.gridx, ty = tile / a.gridx;
     const uint2 range = a.ranges[tile];
     const int n = (int)(range.y - range.x);
-    float4 *my = stage_dyn + wave * (64 * 3);
     const float4 *rec4 = reinterpret_cast<const float4 *>(a.rec);
 
     // Per-pixel state: Tr = transmittance so far (it simply stops changing once the pixel is finished), C = colour,
@@ -145,12 +141,14 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
             const uint32_t bits = __builtin_amdgcn_readfirstlane(__float_as_uint(r2.z));
             const uint32_t pos = (uint32_t)(base + j + 1);
             const StagedConic kc = {r0.z, r0.w, r1.x};
-            const RowTerms rt = splat_row_terms(kc, r0.y - fy[0]);   // NPX == 2: both blocks lie in one row of the tile
+            // blocks side by side share dy: the terms of the exponent without dx once per row of blocks (gsr_device.h)
+            const RowTerms rt = splat_row_terms(kc, r0.y - fy[0]);
+            const RowTerms rt1 = NPX == 4 ? splat_row_terms(kc, r0.y - fy[NPX - 1]) : rt;
             unsigned long long any_stop = 0ull;       // lanes finishing at this splat
             auto block_body = [&](int q) __attribute__((always_inline)) {
-                const float dx = r0.x - fx[q], dy = r0.y - fy[q];
+                const float dx = r0.x - fx[q];
                 float araw;                                          // the one evaluation both passes share (gsr_device.h)
-                const unsigned long long okm = splat_alpha(NPX == 2 ? splat_power_log2_row(kc, rt, dx) : splat_power_log2(kc, dx, dy), r1.y, araw);
+                const unsigned long long okm = splat_alpha(splat_power_log2_row(kc, (NPX == 4 && q >= 2) ? rt1 : rt, dx), r1.y, araw);
                 const float alpha = fminf(GSR_ALPHA_MAX, araw);
                 const float aT = alpha * Tr[q];
                 const float Tn = Tr[q] - aT;                         // = T (1 - alpha)
@@ -191,8 +189,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
         atomicAdd(&a.counters->lanes_past_last, c_past); atomicAdd(&a.counters->lanes_below_alpha, c_alpha);
         atomicAdd(&a.counters->dead_block_visits, c_dead); atomicAdd(&a.counters->waves, 1ull);
         }
-        if (a.counters->trace && (unsigned long long)unit < a.counters->trace_cap)
-            a.counters->trace[unit] = make_uint4((uint32_t)t_start, (uint32_t)wall_clock64(), (uint32_t)c_staged,
+        if (a.counters->trace && (unsigned long long)trace_id < a.counters->trace_cap)
+            a.counters->trace[trace_id] = make_uint4((uint32_t)t_start, (uint32_t)wall_clock64(), (uint32_t)c_staged,
                                                  (uint32_t)min(c_visits, 4095ull) | (__builtin_amdgcn_s_getreg(30724) & 0xffffu) << 12 |   // HW_ID[15:0]: wave, simd, pipe, cu, sh, se
                                                  (__builtin_amdgcn_s_getreg(6164) & 0xfu) << 28);                                           // XCC_ID
     }
@@ -232,6 +230,19 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
             a.out_color[2 * HW + pix] = C2[q] + Tf * bg2;
         }
     }
+}
+
+// classic decomposition: one wave per NPX blocks of a tile, XCD-banded
+template <int NPX, int COUNT>
+__global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int nblocks_padded, int exact_cull) {
+    constexpr int UNITS_PER_TILE = 4 / NPX;
+    extern __shared__ __align__(16) float4 stage_dyn[];     // [waves per block][64 * 3]
+    const int T = a.gridx * a.gridy;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int unit = xcd_band_unit_f(blockIdx.x, nblocks_padded) * wpb + wave;
+    const int tile = unit / UNITS_PER_TILE, sub = unit % UNITS_PER_TILE;
+    if (tile >= T) return;                            // wave-uniform
+    fwd_unit<NPX, COUNT>(a, stage_dyn + wave * (64 * 3), lane, tile, sub, unit, exact_cull);
 }
 
 template <int NPX>

@@ -17,9 +17,10 @@
  *     on the current HIP device unless marked (host).  NULL means "not provided".
  *   - all floating point data is float32; the caller owns every buffer (PyTorch's caching
  *     allocator in the Python host); the library never frees or retains pointers across calls.
- *   - work is enqueued on `stream` (torch's current stream).  gsr_forward synchronises the
- *     stream once (it must read the number of (Gaussian,tile) pairs to size the binning
- *     workspace); gsr_backward never synchronises unless debug != 0.
+ *   - work is enqueued on `stream` (torch's current stream).  gsr_forward waits ONCE, in the middle of the call, for the device to
+ *     have counted the (Gaussian,tile) pairs (the binning workspace is sized from that count): it polls a pinned host word the
+ *     counting kernel writes -- no stream synchronisation, the kernels queued behind keep running -- and falls back to
+ *     hipStreamSynchronize if nothing arrives within 2 s.  gsr_backward never waits unless debug != 0.
  *   - return value: 0 on success, a GSR_ERR_* code otherwise; gsr_last_error() gives the text
  *     (thread-local).  The library never aborts the process and leaves the device usable, because
  *     callers catch RuntimeError and continue (train_stacked_transformer.py:392-398).
@@ -76,8 +77,9 @@ int32_t gsr_backward_workspace_bytes(int32_t P, int64_t R, size_t *bytes);
  * small tables, E = (Gaussian, super-tile) entries, which only the device knows. */
 int32_t gsr_binning_bytes(int64_t N, int32_t W, int32_t H, size_t *bytes);
 
-/* Forward: per-Gaussian projection + SH (S1-S6), scan, key emission (S7), radix sort,
- * tile ranges (S8), front-to-back compositing (S9).
+/* Forward: per-Gaussian projection + SH (S1-S6); per-tile depth-ordered lists (S7-S8: by default (Gaussian, super-tile) entries binned
+ * per super-tile and ordered in LDS, csrc/supertile_sort.hip -- no global sort; round 1's depth order + tile lists or a rocPRIM radix
+ * sort of the pairs when a frame does not fit that path or an option asks for it: the same lists); front-to-back compositing (S9).
  *   P Gaussians, D active SH degree (0..3), M stored SH coefficients per channel,
  *   W x H image.  Exactly one of shs / colors_precomp and exactly one of
  *   (scales, rotations) / cov3D_precomp must be non-NULL.
@@ -177,10 +179,13 @@ int32_t gsr_debug_read_wave_trace(int32_t which, uint32_t *out /*[4 * max_units]
  *   "two_level_sort" (default 1): put the Gaussians in (depth bits, id) order first, emit the pairs in that
  *        order and finish with a STABLE radix sort on the tile id only; identical resulting order to
  *        0 = one global radix sort on tile<<32|depth.  Speed only.
- *   "tile_lists" (default 1): build the per-tile lists from (Gaussian, super-tile) entries (csrc/tile_lists.hip)
- *        instead of emitting and radix-sorting (tile, Gaussian) pairs; needs two_level_sort = 1 and an image of at
- *        most 512 super-tiles of 128 x 128 pixels, otherwise the sort path runs.  Same per-tile lists; point_list
- *        is then laid out super-tile-major (ranges[] say where each tile's slice is).  Speed only.
+ *   "tile_lists" (0, 1 or 2; default 2): how the per-tile lists are built.  2 = csrc/supertile_sort.hip: (Gaussian, 64 x 64 px
+ *        super-tile) entries binned per super-tile, every bin ordered by (depth, id) in LDS and expanded into its 16 tile lists --
+ *        no global sort (needs two_level_sort = 1, <= 8192 super-tiles, a bin of <= 14336 entries and <= 4 entries per Gaussian on
+ *        average; a frame that does not fit takes 1).  1 = round 1's path: bucketed global depth order (csrc/depth_order.hip) +
+ *        csrc/tile_lists.hip (<= 512 super-tiles of 128 x 128 px, else 0).  0 = key emission + rocPRIM radix sort + range detection.
+ *        Same per-tile lists in every case; with 1 and 2 point_list is laid out super-tile-major (ranges[] say where each tile's
+ *        slice is).  Speed only.
  *   "depth_log_map" (default 0, set by the library itself): the depth buckets are cut linearly in depth (0) or in the
  *        depth's float bits, i.e. logarithmically, with 4x the buckets (1).  The library switches to 1 after a frame
  *        overflowed a bucket (far outliers); exposed for tests.
@@ -191,7 +196,20 @@ int32_t gsr_debug_read_wave_trace(int32_t which, uint32_t *out /*[4 * max_units]
  *        kernels.  The waves never synchronise, so 1 lets every wave retire (and be replaced) alone.
  *   "fwd_blocks_per_wave", "bwd_blocks_per_wave" (1, 2 or 4; default 2): 8x8 pixel blocks one
  *        wave64 of the forward / reverse compositing kernel owns (4 = a whole 16x16 tile).  Speed only.
- *   "count_lanes" (default 0): instrumented compositing kernels, see gsr_debug_read_lane_counters.
+ *   "count_lanes" (0, 1 or 2; default 0): instrumented compositing kernels: 1 = lane-slot accounting (gsr_debug_read_lane_counters;
+ *        several times slower), 2 = wave timeline only (gsr_debug_read_wave_trace; normal speed).
+ *   "persistent_bwd" (0, 1 or 2; default 2): the reverse compositing kernel as persistent waves drawing work units -- (half tile, list
+ *        segment) -- longest first from per-XCD lists (csrc/composite_bwd.hip): 0 never, 1 always, 2 on images of at most 6144 tiles,
+ *        whose half tiles fill the chip less than 1.5 times and whose longest list, not the throughput, sets the kernel's time.
+ *        Needs bwd_blocks_per_wave = 2.  Speed only.
+ *   "segment_entries" (0 or a multiple of 64; default 256): while the persistent reverse kernel is in use, the forward pass records a
+ *        checkpoint (transmittance so far, colour behind) per pixel every so many list entries, so that the reverse pass of a long
+ *        list is split into pieces that different waves work off.  0 = whole half tiles.  Needs fwd_blocks_per_wave = 2.
+ *        Gradients equal the unsegmented ones up to the order of float additions.
+ *   "fill_in_tail" (default 0): let the persistent reverse kernel's idle waves write the zero gradient rows of Gaussians without a
+ *        gradient (measured slower; kept for experiments).
+ *   Options that change what the forward pass leaves for the reverse pass ("persistent_bwd", "segment_entries", the blocks-per-wave
+ *   settings) must not be changed between a gsr_forward and the gsr_backward that belongs to it.
  *   "deterministic_bwd" (default 0): the reverse compositing pass stores the partial gradients of every (wave, pair)
  *        into a slot of its own and a second kernel adds each Gaussian's slots in a fixed order, instead of float
  *        atomics whose order differs from run to run: bitwise reproducible gradients (race detection).
