@@ -103,8 +103,7 @@ __device__ __forceinline__ void fwd_unit(const CompositeArgs &a, float4 *my, con
         bool live = false;
         if (lane < cnt && GSR_IDX_OK((size_t)range.x + base + lane, a.contrib_stride, a.seg.hdr + GSR_DBG_SEG_WORD, GSR_BOUND_FWD_LIST_READ)) {
             const uint32_t g = a.point_list[range.x + base + lane];
-            float4 r0 = rec4[3 * (size_t)g], r1 = rec4[3 * (size_t)g + 1];
-            const float4 r2 = rec4[3 * (size_t)g + 2];
+            const float4 r0 = rec4[3 * (size_t)g], r1 = rec4[3 * (size_t)g + 1], r2 = rec4[3 * (size_t)g + 2];
             uint32_t bits = (1u << NPX) - 1u;
             if (exact_cull && r2.z > 0.f) {           // tau == 0: forward ran with culling off -> no information
                 const float invA = 1.f / r0.z, invC = 1.f / r1.x;
@@ -124,9 +123,11 @@ __device__ __forceinline__ void fwd_unit(const CompositeArgs &a, float4 *my, con
                 a.contrib[(size_t)blk * a.contrib_stride + range.x + base + lane] = (uint8_t)((bits >> q) & 1u);
             }
             // (px, py, -0.5*log2e*A, -log2e*B) (-0.5*log2e*C, opacity, r, g) (b, -, block bits, -)
+            // (built as new vectors: overwriting components of the loaded ones sent them through scratch memory, 16 bytes of private
+            //  segment per lane and its set-up at every wave's start)
             const StagedConic sc = stage_conic(r0.z, r0.w, r1.x);
-            r0.z = sc.a; r0.w = sc.b; r1.x = sc.c;
-            my[lane * 3 + 0] = r0; my[lane * 3 + 1] = r1;
+            my[lane * 3 + 0] = make_float4(r0.x, r0.y, sc.a, sc.b);
+            my[lane * 3 + 1] = make_float4(sc.c, r1.y, r1.z, r1.w);
             my[lane * 3 + 2] = make_float4(r2.x, 0.f, __uint_as_float(bits), 0.f);
         }
         uint64_t todo = __ballot(live);

@@ -19,7 +19,7 @@ tot = collections.defaultdict(lambda: collections.defaultdict(float))
 
 def instrumented(name):
     """bench.py's single lane-counting render runs the <NPX, true, ...> compositing instantiations: not the timed kernels."""
-    return "composite_" in name and re.search(r"kernel<\d+, true", name) is not None
+    return "composite_" in name and re.search(r"kernel<\d+, [12]\b", name) is not None
 
 
 import statistics
