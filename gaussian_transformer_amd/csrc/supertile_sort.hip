@@ -31,7 +31,10 @@ namespace gsr {
 #define SS_BIN_THREADS 1024          // workgroup size of the counting / scatter kernels
 #endif
 #define SS_NSUB 512               // depth sub-buckets of one bin
+#define SS_NSPLIT 256             // sub-buckets under the splitter map (ss_sort_expand_kernel)
 #define SS_RANK_MAX 96            // largest sub-bucket the depth-linear map may produce before the bit-linear map takes over
+#define SS_RANK_MAX_LOG 1024       // ... and the bit-linear map before the splitter map does: depths that coincide by the thousand only (the
+                                  // splitter map's binary searches cost more than ranking a sub-bucket of a few hundred: config 4, 107 vs 62 us)
 
 SuperSortPlan super_sort_plan(int P, int W, int H) {
     SuperSortPlan p;
@@ -370,6 +373,11 @@ struct SsSortArgs {
     const uint4 *entries;
     uint32_t *point_list;
     uint2 *ranges;
+    int n_lo, n_hi;          // this launch takes the bins with n_lo <= entries <= n_hi (a frame with a few crowded super-tiles runs the
+                             // small-buffer instantiation over the rest and the big one over those only)
+    uint32_t *unsplit;       // [S] crowded bins the split kernel could not cut into parts (cleared by the first launch, set by the split
+                             // kernel, read by the big-buffer launch, which then takes only those); lives in the counting scratch (wg_cnt)
+    int flagged_only;        // big-buffer launch: 1 = only bins with unsplit[s] != 0
 };
 template <int CAP>
 __global__ __launch_bounds__(SS_THREADS, CAP <= GSR_SS_CAP ? 8 : 4) void ss_sort_expand_kernel(SsSortArgs a) {
@@ -380,10 +388,16 @@ __global__ __launch_bounds__(SS_THREADS, CAP <= GSR_SS_CAP ? 8 : 4) void ss_sort
     __shared__ uint32_t wred[3][SS_THREADS / 64];
     __shared__ uint32_t s_kmin, s_kmax, s_before;
     __shared__ uint32_t tile_start[16];
+    __shared__ uint64_t split[SS_NSPLIT];                          // third map: splitters drawn from the bin itself (split[0] unused); 256 of them:
+                                                                   // with 512 the static LDS would push two workgroups past a CU's 160 KB
     if (a.hdr[DO_OVERFLOW]) return;                                // grid-uniform
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t e0 = a.bin_start[s];
     int n = (int)a.bin_cur[s];                                     // entries actually written (empty masks were dropped)
+    if (a.n_lo == 0 && tid == 0 && a.unsplit) a.unsplit[s] = 0u;   // first launch of the frame: clear the flag of every bin
+    if (n < a.n_lo || n > a.n_hi) return;                          // workgroup-uniform: another launch's bin
+    if (a.flagged_only && a.unsplit[s] == 0u) return;              // the split kernel took it
+
     if (!GSR_IDX_OK(n, CAP + 1, a.hdr + GSR_DBG_GEOM_WORD, GSR_BOUND_SS_BIN_SIZE)) n = CAP;      // debug build: a bin beyond the LDS buffer
     // pairs of the super-tiles before this one = where its region of point_list starts
     {
@@ -426,8 +440,17 @@ __global__ __launch_bounds__(SS_THREADS, CAP <= GSR_SS_CAP ? 8 : 4) void ss_sort
     const float dmin = __uint_as_float(s_kmin);
     const float fspan = __uint_as_float(s_kmax) - dmin;
     const float fscale = (s_kmax > s_kmin && fspan > 0.f) ? (float)SS_NSUB / fspan : 0.f;
-    bool log_map = false;                                              // workgroup-uniform
+    bool log_map = false, split_map = false;                           // workgroup-uniform
     auto sub_of = [&](uint64_t k) -> uint32_t {
+        if (split_map) {                                               // number of splitters <= k: binary search over split[1..SS_NSPLIT)
+            uint32_t lo = 0u, hi = SS_NSPLIT - 1u;                     // answer in [lo, hi]
+#pragma unroll
+            for (int it = 0; it < 8; it++) {                           // SS_NSPLIT = 256
+                const uint32_t mid = (lo + hi + 1u) >> 1;
+                if (split[mid] <= k) lo = mid; else hi = mid - 1u;
+            }
+            return lo;
+        }
         const uint32_t kb = (uint32_t)(k >> 32);
         if (log_map) return (uint32_t)(((uint64_t)(kb - kmin0) * (uint64_t)SS_NSUB) / kspan);     // < SS_NSUB
         const float v = (__uint_as_float(kb) - dmin) * fscale;
@@ -435,20 +458,42 @@ __global__ __launch_bounds__(SS_THREADS, CAP <= GSR_SS_CAP ? 8 : 4) void ss_sort
         return f < SS_NSUB ? f : SS_NSUB - 1u;
     };
     if (n > 0) {
-        // ---- sub-bucket histogram (twice if the linear map turns out lopsided), exclusive scan, placement ----
-        for (int attempt = 0; attempt < 2; attempt++) {
+        // ---- sub-bucket histogram (again if the map turns out lopsided: linear in depth, then linear in the depth bits, then splitters
+        //      drawn from the bin's own keys), exclusive scan, placement ----
+        for (int attempt = 0; attempt < 3; attempt++) {
 #pragma unroll
             for (int q = 0; q < ITEMS; q++)
                 if (tid + q * SS_THREADS < n) atomicAdd(&start[sub_of(key[q])], 1u);
             __syncthreads();
-            if (attempt == 1) break;
+            if (attempt == 2) break;
             const uint32_t mx = ss_wave_max(tid < SS_NSUB ? start[tid] : 0u);
             if (lane == 0) wred[1][w] = mx;
             __syncthreads();
             uint32_t m = 0;
             for (int k = 0; k < SS_THREADS / 64; k++) m = max(m, wred[1][k]);
-            if (m <= SS_RANK_MAX) break;                               // workgroup-uniform
-            log_map = true;
+            if (m <= (attempt == 0 ? SS_RANK_MAX : SS_RANK_MAX_LOG)) break;      // workgroup-uniform
+            if (attempt == 0) log_map = true;
+            else {
+                // Both analytic maps leave a sub-bucket of hundreds (a scene seen from inside: a few splats at the lens stretch the range and
+                // the object sits in a sliver of it; config 4: 590 of a bin's 1781 entries in one sub-bucket, the ranking below is quadratic in
+                // that).  Third map: the first min(n, 1024) entries -- arrival order is arbitrary, so they are a random sample -- are ranked
+                // among themselves and every (ns / 256)-th becomes a splitter; keys are unique (depth bits | id), so the sub-buckets come
+                // out even whatever the depths are, coinciding ones included.
+                const int ns = min(n, SS_THREADS);
+                uint64_t *samp = buf, *sorted = buf + SS_THREADS;      // buf is not in use yet (CAP >= 2 * SS_THREADS)
+                samp[tid] = tid < ns ? key[0] : ~0ull;
+                __syncthreads();
+                if (tid < ns) {
+                    const uint64_t me = samp[tid];
+                    uint32_t r = 0u;
+#pragma unroll 8
+                    for (int u = 0; u < ns; u++) r += samp[u] < me ? 1u : 0u;
+                    sorted[r] = me;
+                }
+                __syncthreads();
+                if (tid >= 1 && tid < SS_NSPLIT) split[tid] = sorted[min(ns - 1, (tid * ns) / SS_NSPLIT)];
+                split_map = true; log_map = false;
+            }
             __syncthreads();
             if (tid <= SS_NSUB) start[tid] = 0u;
             __syncthreads();
@@ -487,8 +532,17 @@ __global__ __launch_bounds__(SS_THREADS, CAP <= GSR_SS_CAP ? 8 : 4) void ss_sort
                 const uint64_t me = buf[j];
                 const uint32_t sb = sub_of(me);
                 const uint32_t a0 = start[sb], a1 = start[sb + 1];
-                uint32_t r = a0;
-                for (uint32_t k = a0; k < a1; k++) r += buf[k] < me ? 1u : 0u;
+                // (eight reads in flight: one LDS round trip per comparison made this loop the whole kernel on scenes whose depths
+                //  crowd a few sub-buckets -- config 4: 170 of 216 us)
+                uint32_t r = a0, k = a0;
+                for (; k + 8 <= a1; k += 8) {
+                    uint64_t v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) v[u] = buf[k + u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) r += v[u] < me ? 1u : 0u;
+                }
+                for (; k < a1; k++) r += buf[k] < me ? 1u : 0u;
                 rk[q] = r; id[q] = (uint32_t)me; mm[q] = mbuf[j];
             }
         }
@@ -574,6 +628,248 @@ __global__ __launch_bounds__(SS_THREADS, CAP <= GSR_SS_CAP ? 8 : 4) void ss_sort
     }
 }
 
+// ---- 4b: a crowded super-tile (GSR_SS_CAP < n <= GSR_SS_CAP_BIG entries: a dense cloud centre) cut across SS_SPLIT_PARTS workgroups.
+// One workgroup ordering such a bin alone takes ~60 us (config 4: the whole stage was that bin).  The parts share nothing at run
+// time: every part reads ALL the bin's entries (224 KB), builds the same sub-bucket histogram, cuts the sub-buckets into PARTS
+// contiguous groups of about n / PARTS entries each -- the same cut in every part, it is a function of the histogram -- and then
+// orders and expands only its own group; where its entries start in each tile's list follows from what it saw of the groups
+// before it (per-tile counts of their mask bits).  A bin whose histogram does not cut that way (one sub-bucket beyond the LDS
+// buffer: thousands of equal depths) is flagged and left to the single-workgroup kernel.
+#define SS_SPLIT_PARTS 4
+template <int PARTS>
+__global__ __launch_bounds__(SS_THREADS, 4) void ss_sort_expand_split_kernel(SsSortArgs a) {
+    constexpr int CAP = GSR_SS_CAP, ITEMS = GSR_SS_CAP_BIG / SS_THREADS, ITEMS_P = CAP / SS_THREADS;
+    extern __shared__ uint64_t buf[];                              // [CAP] keys of this part; later: sorted ids (u32) | sorted masks (u16)
+    uint16_t *mbuf = reinterpret_cast<uint16_t *>(buf + CAP);
+    __shared__ uint32_t start[SS_NSUB + 1], cur[SS_NSUB];
+    __shared__ uint32_t wred[3][SS_THREADS / 64];
+    __shared__ uint32_t s_kmin, s_kmax, s_before;
+    __shared__ uint32_t tile_start[16], tile_before[16];
+    __shared__ uint32_t s_g[PARTS + 1];
+    __shared__ uint32_t wsum[2][SS_THREADS / 64][8];
+    if (a.hdr[DO_OVERFLOW]) return;                                // grid-uniform
+    const int s = blockIdx.x / PARTS, part = blockIdx.x % PARTS, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t e0 = a.bin_start[s];
+    const int n = (int)a.bin_cur[s];
+    if (n <= GSR_SS_CAP || n > GSR_SS_CAP_BIG) return;             // workgroup-uniform: not a crowded bin
+    {
+        uint32_t before = 0;
+        for (int k = tid; k < s; k += SS_THREADS) before += a.bin_pairs[k];
+        before = ss_wave_sum(before);
+        if (lane == 0) wred[0][w] = before;
+    }
+    if (tid <= SS_NSUB) start[tid] = 0u;
+    if (tid <= PARTS) s_g[tid] = tid == 0 ? 0u : (uint32_t)SS_NSUB;
+    uint64_t key[ITEMS];
+    uint32_t msk[ITEMS];
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+        const int j = tid + q * SS_THREADS;
+        key[q] = ~0ull; msk[q] = 0u;
+        if (j < n) {
+            const uint4 e = a.entries[e0 + j];
+            key[q] = ((uint64_t)e.x << 32) | e.y; msk[q] = e.z;
+            kmin = min(kmin, e.x); kmax = max(kmax, e.x);
+        }
+    }
+    kmin = ss_wave_min(kmin); kmax = ss_wave_max(kmax);
+    if (lane == 0) { wred[1][w] = kmin; wred[2][w] = kmax; }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t b = 0, mn = 0xffffffffu, mx = 0u;
+        for (int k = 0; k < SS_THREADS / 64; k++) { b += wred[0][k]; mn = min(mn, wred[1][k]); mx = max(mx, wred[2][k]); }
+        s_before = b; s_kmin = mn; s_kmax = mx;
+    }
+    __syncthreads();
+    const uint32_t kmin0 = s_kmin;
+    const uint64_t kspan = (uint64_t)(s_kmax >= s_kmin ? s_kmax - s_kmin : 0u) + 1ull;
+    const float dmin = __uint_as_float(s_kmin);
+    const float fspan = __uint_as_float(s_kmax) - dmin;
+    const float fscale = (s_kmax > s_kmin && fspan > 0.f) ? (float)SS_NSUB / fspan : 0.f;
+    bool log_map = false;                                              // workgroup-uniform
+    auto sub_of = [&](uint64_t k) -> uint32_t {                        // the maps of ss_sort_expand_kernel
+        const uint32_t kb = (uint32_t)(k >> 32);
+        if (log_map) return (uint32_t)(((uint64_t)(kb - kmin0) * (uint64_t)SS_NSUB) / kspan);
+        const float v = (__uint_as_float(kb) - dmin) * fscale;
+        const uint32_t f = v > 0.f ? (uint32_t)v : 0u;
+        return f < SS_NSUB ? f : SS_NSUB - 1u;
+    };
+    for (int attempt = 0; attempt < 2; attempt++) {
+#pragma unroll
+        for (int q = 0; q < ITEMS; q++)
+            if (tid + q * SS_THREADS < n) atomicAdd(&start[sub_of(key[q])], 1u);
+        __syncthreads();
+        if (attempt == 1) break;
+        const uint32_t mx = ss_wave_max(tid < SS_NSUB ? start[tid] : 0u);
+        if (lane == 0) wred[1][w] = mx;
+        __syncthreads();
+        uint32_t m = 0;
+        for (int k = 0; k < SS_THREADS / 64; k++) m = max(m, wred[1][k]);
+        if (m <= SS_RANK_MAX) break;                                   // workgroup-uniform
+        log_map = true;
+        __syncthreads();
+        if (tid <= SS_NSUB) start[tid] = 0u;
+        __syncthreads();
+    }
+    {
+        const uint32_t v = tid < SS_NSUB ? start[tid] : 0u;
+        const uint32_t incl = ss_wave_incl_scan(v, lane);
+        if (lane == 63) wred[0][w] = incl;
+        __syncthreads();
+        uint32_t ex = incl - v;
+        for (int k = 0; k < w; k++) ex += wred[0][k];
+        if (tid < SS_NSUB) start[tid] = ex;
+        if (tid == SS_NSUB) start[SS_NSUB] = (uint32_t)n;
+    }
+    __syncthreads();
+    // the cut: group p starts at the first sub-bucket whose first position is at or beyond p n / PARTS
+    if (tid < SS_NSUB) {
+#pragma unroll
+        for (int p = 1; p < PARTS; p++) {
+            const uint32_t target = (uint32_t)(((uint64_t)n * p) / PARTS);
+            if (start[tid] >= target && (tid == 0 || start[tid - 1] < target)) s_g[p] = (uint32_t)tid;
+        }
+    }
+    __syncthreads();
+    bool fits = true;
+#pragma unroll
+    for (int p = 0; p < PARTS; p++) fits = fits && (start[s_g[p + 1]] - start[s_g[p]] <= (uint32_t)CAP) && s_g[p] <= s_g[p + 1];
+    if (!fits) {                                                       // workgroup-uniform, and the same in every part
+        if (part == 0 && tid == 0) a.unsplit[s] = 1u;
+        return;
+    }
+    const uint32_t g0 = s_g[part], g1 = s_g[part + 1];
+    const uint32_t base0 = start[g0];
+    const int np = (int)(start[g1] - base0);                           // entries of this part
+    if (tid < SS_NSUB) cur[tid] = start[tid] - base0;                  // only [g0, g1) is used
+    __syncthreads();
+    // own entries into LDS; what the bin's entries of the groups before this one, and all of them, put into each tile
+    auto spread8 = [](uint32_t x) {
+        x = (x | (x << 12)) & 0x000f000fu; x = (x | (x << 6)) & 0x03030303u; x = (x | (x << 3)) & 0x11111111u;
+        return x;
+    };
+    uint32_t tlo = 0u, thi = 0u, blo = 0u, bhi = 0u;                   // nibble counters (<= ITEMS < 16 per thread)
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++)
+        if (tid + q * SS_THREADS < n) {
+            const uint32_t sb = sub_of(key[q]);
+            const uint32_t lo = spread8(msk[q] & 0xffu), hi = spread8(msk[q] >> 8);
+            tlo += lo; thi += hi;
+            if (sb < g0) { blo += lo; bhi += hi; }
+            else if (sb < g1) {
+                const uint32_t pos = atomicAdd(&cur[sb], 1u);
+                if (GSR_IDX_OK(pos, CAP, a.hdr + GSR_DBG_GEOM_WORD, GSR_BOUND_SS_LDS_POS)) { buf[pos] = key[q]; mbuf[pos] = (uint16_t)msk[q]; }
+            }
+        }
+    {   // workgroup sums of the per-tile counts, two tiles to a word (<= 14 336 < 2^16 each)
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int sh = 8 * (k & 3);
+            const uint32_t ts = k < 4 ? tlo : thi, bs = k < 4 ? blo : bhi;
+            const uint32_t tw = ((ts >> sh) & 0xfu) | (((ts >> (sh + 4)) & 0xfu) << 16);
+            const uint32_t bw = ((bs >> sh) & 0xfu) | (((bs >> (sh + 4)) & 0xfu) << 16);
+            const uint32_t tsum = ss_wave_sum(tw), bsum = ss_wave_sum(bw);
+            if (lane == 0) { wsum[0][w][k] = tsum; wsum[1][w][k] = bsum; }
+        }
+    }
+    __syncthreads();
+    if (tid < 16) {
+        uint32_t tot = 0u, bef = 0u;
+        for (int k = 0; k < SS_THREADS / 64; k++) {
+            tot += (wsum[0][k][tid >> 1] >> (16 * (tid & 1))) & 0xffffu;
+            bef += (wsum[1][k][tid >> 1] >> (16 * (tid & 1))) & 0xffffu;
+        }
+        uint32_t incl = tot;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if (tid >= d) incl += t;
+        }
+        const uint32_t st = s_before + incl - tot;
+        tile_start[tid] = st; tile_before[tid] = bef;
+        if (part == 0) {
+            const int tx = (s % a.SX) * GSR_SS_TILES + (tid & 3), ty = (s / a.SX) * GSR_SS_TILES + (tid >> 2);
+            if (tx < a.gridx && ty < a.gridy) a.ranges[ty * a.gridx + tx] = make_uint2(st, st + tot);
+        }
+    }
+    __syncthreads();
+    uint32_t *sid = reinterpret_cast<uint32_t *>(buf);
+    uint16_t *smask = reinterpret_cast<uint16_t *>(sid + CAP);
+    {
+        uint32_t rk[ITEMS_P], id[ITEMS_P], mm[ITEMS_P];
+#pragma unroll
+        for (int q = 0; q < ITEMS_P; q++) {
+            const int j = tid + q * SS_THREADS;
+            rk[q] = 0u; id[q] = 0u; mm[q] = 0u;
+            if (j < np) {
+                const uint64_t me = buf[j];
+                const uint32_t sb = sub_of(me);
+                const uint32_t a0 = start[sb] - base0, a1 = start[sb + 1] - base0;
+                uint32_t r = a0, k = a0;
+                for (; k + 8 <= a1; k += 8) {
+                    uint64_t v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) v[u] = buf[k + u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) r += v[u] < me ? 1u : 0u;
+                }
+                for (; k < a1; k++) r += buf[k] < me ? 1u : 0u;
+                rk[q] = r; id[q] = (uint32_t)me; mm[q] = mbuf[j];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < ITEMS_P; q++)
+            if (tid + q * SS_THREADS < np) { sid[rk[q]] = id[q]; smask[rk[q]] = (uint16_t)mm[q]; }
+    }
+    __syncthreads();
+    uint32_t m[ITEMS_P], idv[ITEMS_P];
+    const int jb = tid * ITEMS_P;
+#pragma unroll
+    for (int q = 0; q < ITEMS_P; q++) {
+        const int j = jb + q;
+        m[q] = j < np ? (uint32_t)smask[j] : 0u;
+        idv[q] = j < np ? sid[j] : 0u;
+    }
+    uint32_t c[8];
+    {
+        uint32_t nlo = 0u, nhi = 0u;
+#pragma unroll
+        for (int q = 0; q < ITEMS_P; q++) { nlo += spread8(m[q] & 0xffu); nhi += spread8(m[q] >> 8); }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t src = k < 4 ? nlo : nhi;
+            const int sh = 8 * (k & 3);
+            c[k] = ((src >> sh) & 0xfu) | (((src >> (sh + 4)) & 0xfu) << 16);
+        }
+    }
+    uint32_t ex[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t incl = ss_wave_incl_scan(c[k], lane);
+        ex[k] = incl - c[k];
+        if (lane == 63) wsum[0][w][k] = incl;
+    }
+    __syncthreads();
+    for (int k = 0; k < w; k++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) ex[u] += wsum[0][k][u];
+    }
+    uint32_t pos[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) pos[t] = tile_start[t] + tile_before[t] + ((ex[t >> 1] >> (16 * (t & 1))) & 0xffffu);
+#pragma unroll
+    for (int q = 0; q < ITEMS_P; q++) {
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const uint32_t bitv = (m[q] >> t) & 1u;
+            if (bitv && GSR_IDX_OK(pos[t], a.hdr[SS_HDR_N], a.hdr + GSR_DBG_GEOM_WORD, GSR_BOUND_POINT_LIST)) a.point_list[pos[t]] = idv[q];
+            pos[t] += bitv;
+        }
+    }
+}
+
 static hipError_t ss_set_lds_attr(const void *fn, size_t bytes, std::atomic<uint64_t> &flags) {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -631,15 +927,27 @@ hipError_t launch_super_sort_expand(const GeomView &g, const ImageView &im, uint
     a.S = pl.S; a.SX = pl.SX; a.gridx = (W + GSR_TILE - 1) / GSR_TILE; a.gridy = (H + GSR_TILE - 1) / GSR_TILE;
     a.hdr = v.hdr; a.bin_start = v.bin_start; a.bin_cur = v.bin_cur; a.bin_pairs = v.bin_pairs; a.entries = g.ss_entries;
     a.point_list = point_list; a.ranges = im.ranges;
-    if (maxbin <= GSR_SS_CAP) {
+    a.unsplit = g.ss_wg_cnt;          // the counting scratch is free once the scatter kernel has run (pl.S <= GSR_SS_WGCNT_WORDS)
+    a.flagged_only = 0;
+    {   // bins of up to GSR_SS_CAP entries: 70 KB of LDS, two workgroups per CU
         const size_t lds = (size_t)GSR_SS_CAP * 10;
         const hipError_t e = ss_set_lds_attr(reinterpret_cast<const void *>(ss_sort_expand_kernel<GSR_SS_CAP>), lds, attr_small);
         if (e != hipSuccess) return e;
+        a.n_lo = 0; a.n_hi = GSR_SS_CAP;
         hipLaunchKernelGGL(ss_sort_expand_kernel<GSR_SS_CAP>, dim3(pl.S), dim3(SS_THREADS), lds, s, a);
-    } else {
+    }
+    if (maxbin > GSR_SS_CAP) {   // the crowded ones (a dense cloud centre): cut across four workgroups each ...
+        static std::atomic<uint64_t> attr_split{0};
+        const size_t lds_s = (size_t)GSR_SS_CAP * 10;
+        const hipError_t es = ss_set_lds_attr(reinterpret_cast<const void *>(ss_sort_expand_split_kernel<SS_SPLIT_PARTS>), lds_s, attr_split);
+        if (es != hipSuccess) return es;
+        hipLaunchKernelGGL(ss_sort_expand_split_kernel<SS_SPLIT_PARTS>, dim3(pl.S * SS_SPLIT_PARTS), dim3(SS_THREADS), lds_s, s, a);
+        // ... and what would not cut, in one workgroup with the 140 KB buffer (round 2 ran EVERY bin of such a frame this way)
+        a.flagged_only = 1;
         const size_t lds = (size_t)GSR_SS_CAP_BIG * 10;
         const hipError_t e = ss_set_lds_attr(reinterpret_cast<const void *>(ss_sort_expand_kernel<GSR_SS_CAP_BIG>), lds, attr_big);
         if (e != hipSuccess) return e;
+        a.n_lo = GSR_SS_CAP + 1; a.n_hi = 0x7fffffff;
         hipLaunchKernelGGL(ss_sort_expand_kernel<GSR_SS_CAP_BIG>, dim3(pl.S), dim3(SS_THREADS), lds, s, a);
     }
     return hipGetLastError();
