@@ -328,7 +328,8 @@ def main():
         try:
             pmc = json.load(open(tpath))
             pmc_stale = pmc.get("kernel_source_sha") != kernel_source_sha()
-            if not pmc_stale:
+            # the counter session profiles the default workload only: its per-launch figures say nothing about another config
+            if not pmc_stale and pmc.get("workload", "cfg3_synth_1M_1080p") == args.config:
                 traffic = pmc.get(dominant)
                 insts = pmc.get(dominant + ".insts")
                 if insts and dom_ms > 0:

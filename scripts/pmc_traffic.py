@@ -72,5 +72,6 @@ for _n in sorted(os.listdir(_csrc)):
         _h.update(_n.encode()); _h.update(open(os.path.join(_csrc, _n), "rb").read())
 res["kernel_source_sha"] = _h.hexdigest()[:16]
 res["captured"] = time.strftime("%Y-%m-%d %H:%M:%S")
+res["workload"] = "cfg3_synth_1M_1080p"      # scripts/profile_round.sh runs the default bench.py under the counters
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
