@@ -27,12 +27,125 @@ __device__ __forceinline__ int xcd_band_unit_f(int b, int nblocks_padded) {
     return (b & 7) * chunk + (b >> 3);
 }
 
+// ---- the splat walk of one staged batch, 2 blocks per wave, written out (round 3) ----
+// What the compiler makes of the C++ walk below is bound by the SCALAR unit as much as by the vector one: 31 scalar instructions per
+// splat visit (mask algebra for the per-pair decisions, the set-bit walk, structured-control-flow bookkeeping) against 39 vector
+// ones, and a gfx950 SIMD issues one scalar instruction per 4.2 cycles whatever the number of waves (scripts/valu_rate.hip: s_add_u32
+// 4.24 cycles, v_fma_f32 2.71) -- 131 against ~129 cycles per visit.  Here the decisions narrow EXEC directly (v_cmpx), finished pixels
+// are taken out by one s_not, "some pixel stops at this splat" leaves the straight-line path through s_cbranch_vccnz, and which
+// entries reach which block is a lane mask per block made at staging time (s_bitcmp1_b64 against the entry's index: no
+// v_readfirstlane of the record's bits): 14 scalar and 5 + 16 per block vector instructions per visit.  Arithmetic, operand order
+// and comparison opcodes are those of the C++ walk (same fma contraction): the two produce identical images, bit for bit
+// (tests/test_gpu_parity.py::test_forward_walkers_agree).
+// Staged record of entry j at lds + 48 j: (px, py, a, b) (c, opacity, r, g) (b, ...).  v52..v63 are used by name (the b128 reads need
+// register tuples whose components can be addressed).  Hazards (gfx940 family): v_exp result first read one instruction later;
+// no VALU reads an SGPR a VALU wrote; EXEC is restored by SALU long before the next v_readlane-class instruction (there is none).
+struct WalkState { float T, C0, C1, C2; uint32_t last; };
+__device__ __forceinline__ void walk_batch_2blocks(uint32_t lds, uint32_t pos1, float fx0, float fx1, float fy, unsigned long long &m,
+                                                   unsigned long long &b0m, unsigned long long &b1m, unsigned long long &d0,
+                                                   unsigned long long &d1, WalkState &p0, WalkState &p1) {
+    uint32_t j, pos;
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n"
+        "1:\n"
+        "s_ff1_i32_b64 %[j], %[m]\n"
+        "s_bitset0_b64 %[m], %[j]\n"
+        "v_mad_u32_u24 v61, %[j], 48, %[lds]\n"
+        "ds_read_b128 v[52:55], v61\n"               // px, py, a, b
+        "ds_read_b128 v[56:59], v61 offset:16\n"     // c, opacity, red, green
+        "ds_read_b32 v60, v61 offset:32\n"           // blue
+        "s_add_u32 %[pos], %[j], %[pos1]\n"
+        "s_waitcnt lgkmcnt(2)\n"
+        "v_sub_f32 v61, v53, %[fy]\n"                // dy
+        "v_mul_f32 v62, v61, v55\n"                  // u = b dy
+        "s_waitcnt lgkmcnt(1)\n"
+        "v_mul_f32 v63, v61, v56\n"                  // c dy
+        "v_mul_f32 v63, v61, v63\n"                  // w = (c dy) dy
+        // (py, b, c and dy are dead from here: v53, v55, v56, v61 are the blocks' temporaries)
+        "s_bitcmp1_b64 %[b0m], %[j]\n"
+        "s_cbranch_scc0 2f\n"
+        "s_not_b64 exec, %[d0]\n"
+        "v_sub_f32 v61, v52, %[fx0]\n"             // dx
+        "v_fma_f32 v53, v54, v61, v62\n"             // a dx + u
+        "v_fma_f32 v61, v53, v61, v63\n"             // power (log2 units)
+        "v_exp_f32 v53, v61\n"
+        "v_cmpx_nlt_f32 vcc, 0, v61\n"               // !(power > 0)
+        "v_mul_f32 v53, v57, v53\n"                  // opacity * G  (the v_exp result is first read one instruction after it)
+        "v_cmpx_ngt_f32 vcc, %[amin], v53\n"         // !(alpha < 1/255)
+        "v_min_f32 v55, 0x3f7d70a4, v53\n"           // min(0.99, .)
+        "v_fma_f32 v56, -%[T0], v55, %[T0]\n"        // T (1 - alpha)
+        "v_cmp_gt_f32 vcc, %[tmin], v56\n"           // it would fall below 1e-4: the pixel stops in front of this splat
+        "s_cbranch_vccnz 20f\n"
+        "21:\n"
+        "v_mul_f32 %[T0], %[T0], v55\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_fmac_f32 %[C02], v60, %[T0]\n"
+        "v_fmac_f32 %[C01], v59, %[T0]\n"
+        "v_fmac_f32 %[C00], v58, %[T0]\n"
+        "v_mov_b32 %[T0], v56\n"
+        "v_mov_b32 %[L0], %[pos]\n"
+        "2:\n"
+        "s_bitcmp1_b64 %[b1m], %[j]\n"
+        "s_cbranch_scc0 3f\n"
+        "s_not_b64 exec, %[d1]\n"
+        "v_sub_f32 v61, v52, %[fx1]\n"             // dx
+        "v_fma_f32 v53, v54, v61, v62\n"             // a dx + u
+        "v_fma_f32 v61, v53, v61, v63\n"             // power (log2 units)
+        "v_exp_f32 v53, v61\n"
+        "v_cmpx_nlt_f32 vcc, 0, v61\n"               // !(power > 0)
+        "v_mul_f32 v53, v57, v53\n"                  // opacity * G  (the v_exp result is first read one instruction after it)
+        "v_cmpx_ngt_f32 vcc, %[amin], v53\n"         // !(alpha < 1/255)
+        "v_min_f32 v55, 0x3f7d70a4, v53\n"           // min(0.99, .)
+        "v_fma_f32 v56, -%[T1], v55, %[T1]\n"        // T (1 - alpha)
+        "v_cmp_gt_f32 vcc, %[tmin], v56\n"           // it would fall below 1e-4: the pixel stops in front of this splat
+        "s_cbranch_vccnz 30f\n"
+        "31:\n"
+        "v_mul_f32 %[T1], %[T1], v55\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_fmac_f32 %[C12], v60, %[T1]\n"
+        "v_fmac_f32 %[C11], v59, %[T1]\n"
+        "v_fmac_f32 %[C10], v58, %[T1]\n"
+        "v_mov_b32 %[T1], v56\n"
+        "v_mov_b32 %[L1], %[pos]\n"
+        "3:\n"
+        "s_mov_b64 exec, -1\n"
+        "s_waitcnt lgkmcnt(0)\n"                      // (a visit that blended nothing must not leave the read of v60 in flight)
+        "s_cmp_lg_u64 %[m], 0\n"
+        "s_cbranch_scc1 1b\n"
+        "s_branch 9f\n"
+        // some pixel of the block stops here: it is finished and does not blend; a block with no pixel left takes no further entries
+        "20:\n"
+        "s_or_b64 %[d0], %[d0], vcc\n"
+        "s_andn2_b64 exec, exec, vcc\n"
+        "s_cmp_eq_u64 %[d0], -1\n"
+        "s_cbranch_scc0 21b\n"
+        "s_mov_b64 %[b0m], 0\n"
+        "s_and_b64 %[m], %[m], %[b1m]\n"
+        "s_branch 21b\n"
+        "30:\n"
+        "s_or_b64 %[d1], %[d1], vcc\n"
+        "s_andn2_b64 exec, exec, vcc\n"
+        "s_cmp_eq_u64 %[d1], -1\n"
+        "s_cbranch_scc0 31b\n"
+        "s_mov_b64 %[b1m], 0\n"
+        "s_and_b64 %[m], %[m], %[b0m]\n"
+        "s_branch 31b\n"
+        "9:\n"
+        : [m] "+s"(m), [b0m] "+s"(b0m), [b1m] "+s"(b1m), [d0] "+s"(d0), [d1] "+s"(d1), [j] "=&s"(j), [pos] "=&s"(pos),
+          [T0] "+v"(p0.T), [C00] "+v"(p0.C0), [C01] "+v"(p0.C1), [C02] "+v"(p0.C2), [L0] "+v"(p0.last),
+          [T1] "+v"(p1.T), [C10] "+v"(p1.C0), [C11] "+v"(p1.C1), [C12] "+v"(p1.C2), [L1] "+v"(p1.last)
+        : [lds] "v"(lds), [pos1] "s"(pos1), [fx0] "v"(fx0), [fx1] "v"(fx1), [fy] "v"(fy), [amin] "s"(GSR_ALPHA_MIN), [tmin] "s"(GSR_T_MIN)
+        : "memory", "scc", "vcc", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+}
+
 // COUNT: instrumented instantiations (gsr_set_option("count_lanes", 1 or 2)): 1 = lane-slot accounting (several times slower), see
 // CompositeCounters; 2 = wave timeline only (two clock reads and one store per wave: the kernel runs at its normal speed)
 // One work unit: the NPX blocks `sub` names of `tile`, the whole list.  `trace_id`: where the instrumented builds file the wave's timeline.
-template <int NPX, int COUNT>
+// ASMW: the splat walk is walk_batch_2blocks (NPX == 2, uninstrumented only) instead of the C++ loop
+template <int NPX, int COUNT, bool ASMW = false>
 __device__ __forceinline__ void fwd_unit(const CompositeArgs &a, float4 *my, const int lane, const int tile, const int sub, const int trace_id,
                                          const int exact_cull) {
+    static_assert(!ASMW || (NPX == 2 && COUNT == 0), "the written-out walk exists for 2 blocks per wave, uninstrumented");
     constexpr int UNITS_PER_TILE = 4 / NPX;
     const int unit = tile * UNITS_PER_TILE + sub;
     const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
@@ -101,6 +214,7 @@ __device__ __forceinline__ void fwd_unit(const CompositeArgs &a, float4 *my, con
         }
         __builtin_amdgcn_wave_barrier();
         bool live = false;
+        uint32_t mybits = 0u;                         // blocks of this wave the lane's entry can reach
         if (lane < cnt && GSR_IDX_OK((size_t)range.x + base + lane, a.contrib_stride, a.seg.hdr + GSR_DBG_SEG_WORD, GSR_BOUND_FWD_LIST_READ)) {
             const uint32_t g = a.point_list[range.x + base + lane];
             const float4 r0 = rec4[3 * (size_t)g], r1 = rec4[3 * (size_t)g + 1], r2 = rec4[3 * (size_t)g + 2];
@@ -113,6 +227,7 @@ __device__ __forceinline__ void fwd_unit(const CompositeArgs &a, float4 *my, con
                     bits |= block_reachable(r0.x, r0.y, r0.z, r0.w, r1.x, invA, invC, r2.z, bxa[q], bxb[q], bya[q], byb[q]) ? (1u << q) : 0u;
             }
             live = bits != 0u;
+            mybits = bits;
             // "staged with a reachable block": pergauss_bwd.hip writes plain zeros for the Gaussians nobody marks.  A plain byte store:
             // an atomicOr into a shared flag word serialises on the splats that thousands of waves stage (config 4: 0.17 -> 0.60 ms)
             if (live) a.touched[g] = (uint8_t)a.touch_mark;
@@ -133,6 +248,21 @@ __device__ __forceinline__ void fwd_unit(const CompositeArgs &a, float4 *my, con
         uint64_t todo = __ballot(live);
         if (COUNT) c_staged += cnt;
         __builtin_amdgcn_wave_barrier();
+        if constexpr (ASMW) {
+            // which entries reach which block, as lane masks (a finished block takes none); the walk visits the union
+            unsigned long long b0m = (blk_done & 1u) ? 0ull : __builtin_amdgcn_ballot_w64((mybits & 1u) != 0u);
+            unsigned long long b1m = (blk_done & 2u) ? 0ull : __builtin_amdgcn_ballot_w64((mybits & 2u) != 0u);
+            unsigned long long m = b0m | b1m;
+            if (m != 0ull) {
+                WalkState p0 = {Tr[0], C0[0], C1[0], C2[0], last[0]}, p1 = {Tr[1], C0[1], C1[1], C2[1], last[1]};
+                walk_batch_2blocks((uint32_t)(uintptr_t)my, (uint32_t)(base + 1), fx[0], fx[1], fy[0], m, b0m, b1m, done[0], done[1], p0, p1);
+                Tr[0] = p0.T; C0[0] = p0.C0; C1[0] = p0.C1; C2[0] = p0.C2; last[0] = p0.last;
+                Tr[1] = p1.T; C0[1] = p1.C0; C1[1] = p1.C1; C2[1] = p1.C2; last[1] = p1.last;
+                if (done[0] == ~0ull) blk_done |= 1u;
+                if (done[1] == ~0ull) blk_done |= 2u;
+            }
+            todo = 0;
+        }
         while (todo) {
             if (COUNT) c_visits += 1;
             const int j = __builtin_ctzll(todo);
@@ -234,8 +364,8 @@ __device__ __forceinline__ void fwd_unit(const CompositeArgs &a, float4 *my, con
 }
 
 // classic decomposition: one wave per NPX blocks of a tile, XCD-banded
-template <int NPX, int COUNT>
-__global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int nblocks_padded, int exact_cull) {
+template <int NPX, int COUNT, bool ASMW>
+__device__ __forceinline__ void fwd_kernel_body(const CompositeArgs &a, int nblocks_padded, int exact_cull) {
     constexpr int UNITS_PER_TILE = 4 / NPX;
     extern __shared__ __align__(16) float4 stage_dyn[];     // [waves per block][64 * 3]
     const int T = a.gridx * a.gridy;
@@ -243,7 +373,16 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
     const int unit = xcd_band_unit_f(blockIdx.x, nblocks_padded) * wpb + wave;
     const int tile = unit / UNITS_PER_TILE, sub = unit % UNITS_PER_TILE;
     if (tile >= T) return;                            // wave-uniform
-    fwd_unit<NPX, COUNT>(a, stage_dyn + wave * (64 * 3), lane, tile, sub, unit, exact_cull);
+    fwd_unit<NPX, COUNT, ASMW>(a, stage_dyn + wave * (64 * 3), lane, tile, sub, unit, exact_cull);
+}
+template <int NPX, int COUNT>
+__global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int nblocks_padded, int exact_cull) {
+    fwd_kernel_body<NPX, COUNT, false>(a, nblocks_padded, exact_cull);
+}
+// the default instantiation: written-out walk; 8 waves per SIMD asked for explicitly (the walk's twelve named registers + the loop
+// invariants the compiler hoists came to 65 VGPRs without it)
+__global__ __launch_bounds__(256, 8) void composite_fwd_walk_kernel(CompositeArgs a, int nblocks_padded, int exact_cull) {
+    fwd_kernel_body<2, 0, true>(a, nblocks_padded, exact_cull);
 }
 
 template <int NPX>
@@ -257,6 +396,9 @@ static hipError_t launch_fwd(const CompositeArgs &a, int exact_cull, int wpb, hi
                            padded, exact_cull);
     else if (a.counters)
         hipLaunchKernelGGL((composite_fwd_kernel<NPX, 1>), dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4) + (size_t)g_composite_lds_pad, s, a,
+                           padded, exact_cull);
+    else if (NPX == 2 && a.asm_walk)
+        hipLaunchKernelGGL(composite_fwd_walk_kernel, dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4) + (size_t)g_composite_lds_pad, s, a,
                            padded, exact_cull);
     else
         hipLaunchKernelGGL((composite_fwd_kernel<NPX, 0>), dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4) + (size_t)g_composite_lds_pad, s, a,

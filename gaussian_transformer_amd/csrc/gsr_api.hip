@@ -34,6 +34,7 @@ int g_composite_lds_pad = 0;                    // debug: extra dynamic LDS byte
 static std::atomic<int> g_count_lanes{0};      // 1: instrumented compositing kernels (lane-slot accounting, slower)
 static std::atomic<int> g_deterministic_bwd{0};   // 1: fixed-order reduction of the reverse pass's partial gradients
 static std::atomic<int> g_seg_len{256};           // entries per segment of the reverse pass's work units (multiple of 64); 0: whole half tiles
+static std::atomic<int> g_asm_walk{1};            // 1: compositing walks written in gfx950 assembly where they exist (same results, bit for bit), 0: the C++ walks
 static std::atomic<int> g_fill_in_tail{0};        // 1: with the persistent reverse kernel, the zero rows of Gaussians without a gradient are written by its idle waves
                                                   // (measured at config 3: pergauss_bwd 84 -> 62 us, but the compositing kernel + 40..66 us: off)
 static std::atomic<int> g_persistent_bwd{2};      // persistent reverse compositing kernel drawing length-ordered work units (2 blocks per wave only): 0 never, 1 always,
@@ -342,6 +343,7 @@ int32_t gsr_set_option(const char *name, int32_t value) {
         g_persistent_bwd.store(value); return GSR_OK;
     }
     if (name && !strcmp(name, "fill_in_tail")) { g_fill_in_tail.store(value ? 1 : 0); return GSR_OK; }
+    if (name && !strcmp(name, "asm_walk")) { g_asm_walk.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "segment_entries")) {
         if (value < 0 || value > 65536 || (value & 63)) return fail(GSR_ERR_INVALID_ARGUMENT, "segment_entries must be 0 or a multiple of 64 up to 65536");
         g_seg_len.store(value); return GSR_OK;
@@ -376,6 +378,7 @@ int32_t gsr_get_option(const char *name, int32_t *value) {
     if (name && value && !strcmp(name, "persistent_bwd")) { *value = g_persistent_bwd.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "segment_entries")) { *value = g_seg_len.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "fill_in_tail")) { *value = g_fill_in_tail.load(); return GSR_OK; }
+    if (name && value && !strcmp(name, "asm_walk")) { *value = g_asm_walk.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "poll_timeouts")) { *value = dev_state().poll_timeouts.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "depth_buckets")) { *value = g_depth_buckets.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "composite_waves_per_block")) { *value = g_wpb.load(); return GSR_OK; }
@@ -628,6 +631,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     // checkpoints + per-half-tile lengths for the segmented reverse pass: only where gsr_backward will use them (same rule as there)
     const SegPlan sp = seg_plan(W, H);
     ca.seg_len = sp.seg_len;
+    ca.asm_walk = g_asm_walk.load();
     HIP_TRY(launch_composite_fwd(ca, g_fwd_npx.load(), pa.exact_cull, g_wpb.load(), s), "composite launch");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "composite");
     tm.mark(-1);

@@ -17,7 +17,31 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cyc, fl
     float b = seed * 0.5f, c = seed * 0.25f;
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pb = {b, b}, pc = {c, c};
+    unsigned s0 = 0, s1 = 0, s2 = 0, s3 = 0, cnt = 0;
+    unsigned long long m64 = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    // kinds with scalar instructions: the whole loop is one asm statement (scalar values carried around a C loop through asm
+    // outputs count as divergent and land in VGPRs); ITER x 64 instructions as elsewhere
+#define SLOOP(body) "s_mov_b32 %[cnt], 256\n s_mov_b32 %[s0], 1\n s_mov_b32 %[s1], 2\n s_mov_b32 %[s2], 3\n s_mov_b32 %[s3], 4\n s_mov_b64 %[m], -1\n" \
+                    "1:\n .rept 8\n" body ".endr\n s_sub_u32 %[cnt], %[cnt], 1\n s_cmp_lg_u32 %[cnt], 0\n s_cbranch_scc1 1b\n"
+#define SOUT [cnt] "=&s"(cnt), [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [m] "=&s"(m64)
+    if (KIND == 9) {          // scalar ALU only: 4 independent s_add_u32 chains
+        asm volatile(SLOOP("s_add_u32 %[s0], %[s0], 3\n s_add_u32 %[s1], %[s1], 5\n s_add_u32 %[s2], %[s2], 7\n s_add_u32 %[s3], %[s3], 9\n"
+                           "s_add_u32 %[s0], %[s0], 3\n s_add_u32 %[s1], %[s1], 5\n s_add_u32 %[s2], %[s2], 7\n s_add_u32 %[s3], %[s3], 9\n")
+                     : SOUT : : "scc");
+    } else if (KIND == 10) {  // one scalar after every vector instruction
+        asm volatile(SLOOP("v_fma_f32 %[a0], %[a0], %[b], %[c]\n s_add_u32 %[s0], %[s0], 3\n v_fma_f32 %[a1], %[a1], %[b], %[c]\n s_add_u32 %[s1], %[s1], 5\n"
+                           "v_fma_f32 %[a2], %[a2], %[b], %[c]\n s_add_u32 %[s2], %[s2], 7\n v_fma_f32 %[a3], %[a3], %[b], %[c]\n s_add_u32 %[s3], %[s3], 9\n")
+                     : SOUT, [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3) : [b] "v"(b), [c] "v"(c) : "scc");
+    } else if (KIND == 11) {  // the forward compositing loop's mix: 5 vector to 3 scalar
+        asm volatile(SLOOP("v_fma_f32 %[a0], %[a0], %[b], %[c]\n v_fma_f32 %[a1], %[a1], %[b], %[c]\n s_add_u32 %[s0], %[s0], 3\n v_fma_f32 %[a2], %[a2], %[b], %[c]\n"
+                           "s_add_u32 %[s1], %[s1], 5\n v_fma_f32 %[a3], %[a3], %[b], %[c]\n v_fma_f32 %[a4], %[a4], %[b], %[c]\n s_add_u32 %[s2], %[s2], 7\n")
+                     : SOUT, [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4) : [b] "v"(b), [c] "v"(c) : "scc");
+    } else if (KIND == 12) {  // set-bit walk as the compositing kernels do it: s_ff1 + s_bitset0 + v_readlane of the found lane (dependent chain)
+        asm volatile(SLOOP("s_ff1_i32_b64 %[s0], %[m]\n s_bitset0_b64 %[m], %[s0]\n v_readlane_b32 %[s1], %[a0], %[s0]\n s_ff1_i32_b64 %[s2], %[m]\n"
+                           "s_bitset0_b64 %[m], %[s2]\n v_readlane_b32 %[s3], %[a0], %[s2]\n s_or_b64 %[m], %[m], 0xff\n s_add_u32 %[s1], %[s1], %[s3]\n")
+                     : SOUT, [a0] "+v"(a0) : : "scc");
+    } else
     for (int i = 0; i < ITER; i++) {
         if (KIND == 0) {          // v_fma_f32
             REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
@@ -64,7 +88,7 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cyc, fl
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    a0 += p0[0] + p0[1] + p1[0] + p1[1] + p2[0] + p2[1] + p3[0] + p3[1];
+    a0 += p0[0] + p0[1] + p1[0] + p1[1] + p2[0] + p2[1] + p3[0] + p3[1] + (float)(s0 + s1 + s2 + s3 + cnt) + (float)(unsigned)m64;
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
     if ((threadIdx.x & 63) == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
 }
@@ -106,5 +130,10 @@ int main() {
     for (int w : {1, 4}) run<7>("v_rcp_f32", w, 1);
     for (int w : {1, 4}) run<6>("v_add_f32_dpp", w, 1);
     for (int w : {1, 2, 4}) run<8>("v_mfma_16x16x4_f32", w, 2 * 16 * 16 * 4 / 64.0);
+    // scalar instructions: "instructions" below counts scalar and vector alike (TFLOP/s column meaningless)
+    for (int w : {1, 2, 4, 8}) run<9>("s_add_u32", w, 0);
+    for (int w : {1, 2, 4, 8}) run<10>("v_fma,s_add 1:1", w, 1);
+    for (int w : {1, 2, 4, 8}) run<11>("v_fma,s_add 5:3", w, 1.25);
+    for (int w : {1, 2, 4, 8}) run<12>("ff1,bitset0,readlane", w, 0);
     return 0;
 }
