@@ -34,6 +34,7 @@ int g_composite_lds_pad = 0;                    // debug: extra dynamic LDS byte
 static std::atomic<int> g_count_lanes{0};      // 1: instrumented compositing kernels (lane-slot accounting, slower)
 static std::atomic<int> g_deterministic_bwd{0};   // 1: fixed-order reduction of the reverse pass's partial gradients
 static std::atomic<int> g_seg_len{256};           // entries per segment of the reverse pass's work units (multiple of 64); 0: whole half tiles
+static std::atomic<int> g_dense_pergauss{2};      // per-Gaussian backward on the Gaussians with a gradient only, zero rows filled on a second stream: 0 off, 1 on, 2 = from GSR_DENSE_MIN_P Gaussians
 static std::atomic<int> g_asm_walk{1};            // 1: compositing walks written in gfx950 assembly where they exist (same results, bit for bit), 0: the C++ walks
 static std::atomic<int> g_fill_in_tail{0};        // 1: with the persistent reverse kernel, the zero rows of Gaussians without a gradient are written by its idle waves
                                                   // (measured at config 3: pergauss_bwd 84 -> 62 us, but the compositing kernel + 40..66 us: off)
@@ -60,6 +61,10 @@ struct DeviceState {
     std::mutex mu;                                // guards stage_ms and counters
     float stage_ms[GSR_NUM_STAGES] = {0};         // last profiled forward / backward on this device
     CompositeCounters *counters = nullptr;        // [2] device memory: forward, reverse (allocated on first use of count_lanes)
+    // gsr_backward's second stream (lowest priority): the zero-fill of the gradient outputs runs there, beside the compositing kernel
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool side_failed = false;
 };
 static DeviceState g_dev[GSR_MAX_DEVICES];
 static DeviceState &dev_state();
@@ -89,6 +94,22 @@ static DeviceState &dev_state() {
     if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
     return g_dev[d % GSR_MAX_DEVICES];
 }
+// the device's second stream and its two events, made on first use (false: could not be made -- the caller keeps everything on one stream)
+static bool side_stream(DeviceState &ds) {
+    if (ds.side) return true;
+    if (ds.side_failed) return false;
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (hipStreamCreateWithPriority(&ds.side, hipStreamNonBlocking, least) != hipSuccess ||
+        hipEventCreateWithFlags(&ds.ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ds.ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        ds.side = nullptr; ds.side_failed = true;
+        return false;
+    }
+    return true;
+}
+#define GSR_DENSE_MIN_P 500000
 static const char *const k_stage_names[GSR_NUM_STAGES] = {
     // lists.bin = entries binned per super-tile (count + scan + scatter; round 1's path: depth order + scan); lists.order = per-super-tile order +
     // expansion into the tile lists (sort path: the radix sort); emit_keys / ranges only run on the sort path
@@ -344,6 +365,10 @@ int32_t gsr_set_option(const char *name, int32_t value) {
     }
     if (name && !strcmp(name, "fill_in_tail")) { g_fill_in_tail.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "asm_walk")) { g_asm_walk.store(value ? 1 : 0); return GSR_OK; }
+    if (name && !strcmp(name, "dense_pergauss")) {
+        if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARGUMENT, "dense_pergauss must be 0, 1 or 2");
+        g_dense_pergauss.store(value); return GSR_OK;
+    }
     if (name && !strcmp(name, "segment_entries")) {
         if (value < 0 || value > 65536 || (value & 63)) return fail(GSR_ERR_INVALID_ARGUMENT, "segment_entries must be 0 or a multiple of 64 up to 65536");
         g_seg_len.store(value); return GSR_OK;
@@ -379,6 +404,7 @@ int32_t gsr_get_option(const char *name, int32_t *value) {
     if (name && value && !strcmp(name, "segment_entries")) { *value = g_seg_len.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "fill_in_tail")) { *value = g_fill_in_tail.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "asm_walk")) { *value = g_asm_walk.load(); return GSR_OK; }
+    if (name && value && !strcmp(name, "dense_pergauss")) { *value = g_dense_pergauss.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "poll_timeouts")) { *value = dev_state().poll_timeouts.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "depth_buckets")) { *value = g_depth_buckets.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "composite_waves_per_block")) { *value = g_wpb.load(); return GSR_OK; }
@@ -412,7 +438,8 @@ int32_t gsr_backward_workspace_bytes(int32_t P, int64_t R, size_t *bytes) {
     if (P < 0 || R < 0 || !bytes) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward_workspace_bytes: bad argument");
     const size_t acc_bytes = align_up(acc_rows(P) * GSR_ACC_FLOATS * sizeof(float));
     const size_t det_bytes = g_deterministic_bwd.load() ? (size_t)R * (size_t)(4 / g_bwd_npx.load()) * GSR_ACC_FLOATS * sizeof(float) : 0;
-    *bytes = acc_bytes + align_up(det_bytes);
+    // + the dense per-Gaussian stage's list and record buffer (pergauss_bwd.hip), behind the accumulators
+    *bytes = acc_bytes + align_up(det_bytes) + pergauss_vis_bytes(P);
     return GSR_OK;
 }
 
@@ -692,8 +719,43 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     const int pk_grid = persistent ? composite_bwd_persistent_grid(gridx * gridy, det ? 1 : 0, lane_counters(1) ? g_count_lanes.load() : 0) : 0;
     const int fill_chunk = persistent && g_fill_in_tail.load() ? seg_fill_chunk(P) : 0;       // zero-fill units in the persistent kernel's lists
 
+    PergaussBwdArgs pa;
+    pa.raw_params = raw_params ? 1 : 0; pa.shs_rest = shs_rest; pa.rec = g.rec; pa.dL_dsh_rest = dL_dsh_rest;
+    pa.P = P; pa.D = D; pa.M = M; pa.W = W; pa.H = H; pa.means3D = means3D; pa.shs = shs; pa.colors_precomp = colors_precomp;
+    pa.scales = scales; pa.rotations = rotations; pa.cov3D_precomp = cov3D_precomp; pa.viewmatrix = viewmatrix;
+    pa.projmatrix = projmatrix; pa.campos = campos; pa.scale_modifier = scale_modifier; pa.tanfovx = tanfovx;
+    pa.tanfovy = tanfovy; pa.radii = radii; pa.clamped = g.clamped; pa.opac = g.opac; pa.acc = (const float *)bwd_ws; pa.hot = g.hot; pa.touched = g.touched; pa.touch_mark = g.touch_mark;
+    pa.skip_unmarked = fill_chunk > 0 && R > 0 ? 1 : 0;
+    pa.dense = 0; pa.vis_count = nullptr; pa.vis_list = nullptr; pa.vis_rec = nullptr; pa.vis_cap = 0;
+    pa.dL_dmeans2D = dL_dmeans2D; pa.dL_dopacity = dL_dopacity; pa.dL_dcolors = dL_dcolors; pa.dL_dmeans3D = dL_dmeans3D;
+    pa.dL_dcov3D = dL_dcov3D; pa.dL_dsh = dL_dsh; pa.dL_dscales = dL_dscales; pa.dL_drots = dL_drots;
+
     StageTimer tm(s, g_profiling.load() != 0);
     tm.mark(8);
+    // Dense per-Gaussian stage: the zeros of every gradient output are written by a kernel of their own on the device's second stream,
+    // forked here and joined in front of pergauss_bwd: it runs beside the compositing kernel (FP32-issue-bound, the memory system idle).
+    const int dense_opt = g_dense_pergauss.load();
+    const size_t vis_off = align_up(acc_bytes) + align_up(det_bytes);
+    bool dense = R > 0 && fill_chunk == 0 && (dense_opt == 1 || (dense_opt == 2 && P >= GSR_DENSE_MIN_P)) && pergauss_dense_eligible(pa) &&
+                 bwd_bytes >= vis_off + pergauss_vis_bytes(P);            // (a workspace sized before this stage existed: the streaming kernel)
+    if (dense) {
+        char *vis = (char *)bwd_ws + vis_off;
+        pa.vis_count = (uint32_t *)vis;
+        pa.vis_list = (uint32_t *)(vis + 256);
+        pa.vis_rec = (float4 *)(vis + 256 + (((size_t)P * 4 + 255) / 256 * 256));
+        pa.vis_cap = pergauss_vis_cap(P);
+        DeviceState &ds = dev_state();
+        std::lock_guard<std::mutex> lk(ds.mu);
+        if (!side_stream(ds)) dense = false;
+        else {
+            HIP_TRY(hipEventRecord(ds.ev_fork, s), "fork event");
+            HIP_TRY(hipStreamWaitEvent(ds.side, ds.ev_fork, 0), "fork wait");
+            HIP_TRY(hipMemsetAsync(pa.vis_count, 0, 256, ds.side), "visible counter");
+            HIP_TRY(launch_gather_visible(pa, ds.side), "gather launch");
+            HIP_TRY(launch_fill_zero(pa, ds.side), "gradient zero-fill launch");
+            HIP_TRY(hipEventRecord(ds.ev_join, ds.side), "join event");
+        }
+    }
     if (det) {
         HIP_TRY(hipMemsetAsync(bwd_ws, 0, align_up(acc_bytes) + det_bytes, s), "zero accumulators");
         if (persistent) HIP_TRY(launch_zero_marked_rows(P, g.touched, g.touch_mark, (float *)bwd_ws, 0, segv, pk_grid, fill_chunk, s), "unit lists");
@@ -718,15 +780,12 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
         if (debug) HIP_TRY(hipStreamSynchronize(s), "composite backward");
     }
     tm.mark(10);
-    PergaussBwdArgs pa;
-    pa.raw_params = raw_params ? 1 : 0; pa.shs_rest = shs_rest; pa.rec = g.rec; pa.dL_dsh_rest = dL_dsh_rest;
-    pa.P = P; pa.D = D; pa.M = M; pa.W = W; pa.H = H; pa.means3D = means3D; pa.shs = shs; pa.colors_precomp = colors_precomp;
-    pa.scales = scales; pa.rotations = rotations; pa.cov3D_precomp = cov3D_precomp; pa.viewmatrix = viewmatrix;
-    pa.projmatrix = projmatrix; pa.campos = campos; pa.scale_modifier = scale_modifier; pa.tanfovx = tanfovx;
-    pa.tanfovy = tanfovy; pa.radii = radii; pa.clamped = g.clamped; pa.opac = g.opac; pa.acc = (const float *)bwd_ws; pa.hot = g.hot; pa.touched = g.touched; pa.touch_mark = g.touch_mark;
-    pa.skip_unmarked = fill_chunk > 0 && R > 0 ? 1 : 0;
-    pa.dL_dmeans2D = dL_dmeans2D; pa.dL_dopacity = dL_dopacity; pa.dL_dcolors = dL_dcolors; pa.dL_dmeans3D = dL_dmeans3D;
-    pa.dL_dcov3D = dL_dcov3D; pa.dL_dsh = dL_dsh; pa.dL_dscales = dL_dscales; pa.dL_drots = dL_drots;
+    if (dense) {
+        DeviceState &ds = dev_state();
+        std::lock_guard<std::mutex> lk(ds.mu);
+        HIP_TRY(hipStreamWaitEvent(s, ds.ev_join, 0), "join wait");
+        pa.skip_unmarked = 1; pa.dense = 1;
+    }
     HIP_TRY(launch_pergauss_bwd(pa, s), "per-Gaussian backward launch");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "per-Gaussian backward");
     tm.mark(-1);

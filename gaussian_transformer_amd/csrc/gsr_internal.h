@@ -370,9 +370,25 @@ struct PergaussBwdArgs {
     const uint8_t *touched;  // [P] GeomView::touched
     const uint32_t *touch_mark;
     int skip_unmarked;       // 1: the rows of Gaussians without a gradient have been zero-filled already (FillArgs): write nothing for them
+    int dense;               // 1: pergauss_bwd_dense_kernel (needs skip_unmarked: launch_fill_zero and launch_gather_visible have run)
+    uint32_t *vis_count;     // dense: number of Gaussians with a gradient (zeroed before launch_gather_visible)
+    uint32_t *vis_list;      // [P] their indices, in the order the gathering workgroups arrived
+    float4 *vis_rec;         // [vis_cap / 64][15][64] their inputs (pergauss_bwd.hip); entries from vis_cap on are gathered by the dense kernel itself
+    uint32_t vis_cap;        // multiple of 64
     float *dL_dmeans2D, *dL_dopacity, *dL_dcolors, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drots;
 };
 hipError_t launch_pergauss_bwd(const PergaussBwdArgs &a, hipStream_t s);
+hipError_t launch_fill_zero(const PergaussBwdArgs &a, hipStream_t s);      // zeros into every gradient output of `a`
+hipError_t launch_gather_visible(const PergaussBwdArgs &a, hipStream_t s);  // vis_count / vis_list / vis_rec of `a` (vis_count zeroed by the caller)
+bool pergauss_dense_eligible(const PergaussBwdArgs &a);
+// the dense variant's share of the backward workspace: counter line, list, records for up to vis_cap(P) Gaussians
+static inline uint32_t pergauss_vis_cap(int P) {
+    const long long c = (long long)P / 4 > 131072 ? (long long)P / 4 : 131072;
+    return (uint32_t)(((c < (long long)P ? c : (long long)P) + 63) / 64 * 64);
+}
+static inline size_t pergauss_vis_bytes(int P) {
+    return 256 + (((size_t)P * 4 + 255) / 256 * 256) + (size_t)pergauss_vis_cap(P) * 15 * 16;
+}
 
 hipError_t launch_l1_ssim_forward(int C, int H, int W, const float *img, const float *gt, float lambda, float *dmaps,
                                   float *partial, float *out, hipStream_t s);

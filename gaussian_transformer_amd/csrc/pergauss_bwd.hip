@@ -16,33 +16,38 @@ namespace gsr {
 
 // RAW / SPLIT: fused-step extension (raw parameters / split SH tensors) as separate instantiations, so the
 // reference path keeps its register budget.
-template <int D, bool RAW, bool SPLIT>
-__global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.P) return;
+// DENSE: `i` comes from the workgroup's list of Gaussians with a gradient (pergauss_bwd_dense_kernel below): known visible, its rows
+// are not next to its lane neighbours' (no LDS tile), nothing is written for anybody else (the rows were zero-filled, fill_zero_kernel)
+// rows / nrows (DENSE): the wave's 64 list entries in LDS and how many of them exist: lanes beyond take part in copying the
+// wave's dL/dshs rows out (each row to its own Gaussian's place), nothing else
+template <int D, bool RAW, bool SPLIT, bool DENSE>
+__device__ __forceinline__ void pergauss_one(const PergaussBwdArgs &a, const int i_in, float4 *sh_tile_dyn, const uint32_t *rows = nullptr,
+                                             const int nrows = 0, const float4 *pre = nullptr) {
+    if (!DENSE && i_in >= a.P) return;
+    const bool active = !DENSE || (int)(threadIdx.x & 63) < nrows;
+    const int i = active ? i_in : 0;
     const size_t si = (size_t)i;
     constexpr int K = (D + 1) * (D + 1);
     // radii and the flag byte are requested together and awaited together (the asm ties them: left alone, the compiler sinks the
     // byte load below the branch on radii, and the branch on its bit 7 then costs a second memory round trip)
-    int rad = a.radii[si];
-    uint32_t cl = a.clamped[si];         // bits 0-2: SH clamp mask; bit 7: the splat has replica accumulator rows
-    uint32_t tch = a.touched[si];
-    asm volatile("" : "+v"(rad), "+v"(cl), "+v"(tch));
+    int rad = DENSE ? 1 : a.radii[si];
+    uint32_t cl = DENSE ? __float_as_uint(pre[1].w) : a.clamped[si];         // bits 0-2: SH clamp mask; bit 7: the splat has replica accumulator rows
+    uint32_t tch = DENSE ? 0u : a.touched[si];
+    if (!DENSE) asm volatile("" : "+v"(rad), "+v"(cl), "+v"(tch));
     // byte != this frame's mark: no wave of the forward pass staged this Gaussian with a reachable block, so the reverse pass never met
     // it and all its gradients are 0: only the zeros are written (91 % of the Gaussians at config 3, whose dense cloud is mostly occluded)
-    const bool visible = rad > 0 && tch == *a.touch_mark;
-    // skip_unmarked: the persistent reverse compositing kernel has zero-filled the rows of the Gaussians that are not `visible`
-    // (composite_bwd.hip, fill_unit: the same test on the same bytes); nothing is written for them here
+    const bool visible = DENSE ? active : (rad > 0 && tch == *a.touch_mark);
+    // skip_unmarked: the rows of the Gaussians that are not `visible` have been zero-filled already (the persistent reverse compositing
+    // kernel's fill units, composite_bwd.hip, or fill_zero_kernel below); nothing is written for them here
     const bool writes = visible || !a.skip_unmarked;
-    const unsigned long long wave_writes = __builtin_amdgcn_ballot_w64(writes);
+    const unsigned long long wave_writes = DENSE ? 0ull : __builtin_amdgcn_ballot_w64(writes);
     // dL/dshs rows of a whole wave (64 Gaussians x 192 B at M = 16) are contiguous in memory: the lanes put their rows into a
     // wave-private LDS tile and the wave copies the tile out with 16-byte stores at consecutive addresses (12 x 1 KiB), instead
     // of 48 dword stores per lane at a 192-byte stride that leave every 128-byte line half written 48 times over.
     // Wave-uniform: M = 16, not the split layout, 16-byte aligned, every lane of the wave alive.
-    extern __shared__ __align__(16) float4 sh_tile_dyn[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wave_first = blockIdx.x * 256 + wave * 64;
-    const bool tile_path = !(SPLIT) && a.sh_tile && wave_first + 64 <= a.P;
+    const bool tile_path = !(SPLIT) && a.sh_tile && (DENSE || wave_first + 64 <= a.P);
     float4 *tile = sh_tile_dyn + wave * (64 * SH_TILE_ROW);
 
     float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -54,6 +59,41 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
         const float4 *acc4 = reinterpret_cast<const float4 *>(a.acc) + 4 * si;
         float4 A0 = acc4[0], A1 = acc4[1];
         float A8 = a.acc[GSR_ACC_FLOATS * si + 8];
+
+        // DENSE: means, scales, rotation, opacity and the SH row come in `pre`, the Gaussian's record in the compact buffer that
+        // gather_visible_kernel filled while the compositing kernel ran (or that the caller gathered itself): (mean, opacity)
+        // (scale, flags) (rotation) (12 x SH)
+        float p[3], c6[6], s[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, opac, c[3 * K + 3];
+        if (DENSE) {
+            p[0] = pre[0].x; p[1] = pre[0].y; p[2] = pre[0].z; opac = pre[0].w;
+            s[0] = pre[1].x; s[1] = pre[1].y; s[2] = pre[1].z;
+            q[0] = pre[2].x; q[1] = pre[2].y; q[2] = pre[2].z; q[3] = pre[2].w;
+#pragma unroll
+            for (int v = 0; v < (3 * K + 3) / 4; v++) {
+                c[4 * v] = pre[3 + v].x;
+                if (4 * v + 1 < 3 * K + 3) c[4 * v + 1] = pre[3 + v].y;
+                if (4 * v + 2 < 3 * K + 3) c[4 * v + 2] = pre[3 + v].z;
+                if (4 * v + 3 < 3 * K + 3) c[4 * v + 3] = pre[3 + v].w;
+            }
+        } else {
+            p[0] = a.means3D[3 * si]; p[1] = a.means3D[3 * si + 1]; p[2] = a.means3D[3 * si + 2];
+            if (a.cov3D_precomp) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * si + k];
+            } else {
+                s[0] = a.scales[3 * si]; s[1] = a.scales[3 * si + 1]; s[2] = a.scales[3 * si + 2];
+                const float4 q4 = reinterpret_cast<const float4 *>(a.rotations)[si];
+                q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+            }
+            opac = a.opac[si];
+            if (a.shs) {
+                if (SPLIT) load_sh_row_split<K>(a.shs, a.shs_rest, si, a.M, c);
+                else load_sh_row<K>(a.shs, si, a.M, c);
+            }
+        }
+        // DENSE: few waves per SIMD, nobody covers a wave's memory latency: the accumulator row is requested here, with the record
+        // (the compiler may not move a load across the barrier)
+        if (DENSE) asm volatile("" ::: "memory");
         if (cl & 0x80u) {                                     // a splat over hundreds of tiles: its waves added into replica rows
             const uint32_t hot = a.hot[si];
             const size_t first = (size_t)a.P + (hot >> 4);
@@ -66,18 +106,9 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
             }
         }
         dcol[0] = A0.x; dcol[1] = A0.y; dcol[2] = A0.z;
-
-        const float p[3] = {a.means3D[3 * si], a.means3D[3 * si + 1], a.means3D[3 * si + 2]};
         float pv[3];
         xform4x3(a.viewmatrix, p, pv);
-        float c6[6], s[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f};
-        if (a.cov3D_precomp) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * si + k];
-        } else {
-            s[0] = a.scales[3 * si]; s[1] = a.scales[3 * si + 1]; s[2] = a.scales[3 * si + 2];
-            const float4 q4 = reinterpret_cast<const float4 *>(a.rotations)[si];
-            q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+        if (!a.cov3D_precomp) {
             if (RAW) {
                 s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]);
                 act_normalize4(q, q_inv_norm);
@@ -94,7 +125,6 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
         // are applied here:
         //   mean2D gradient w.r.t. NDC = -(W/2, H/2) * conic * sum s*d;   conic gradient = -1/2 * sum s * d d^T;
         //   dL/dopacity = sum G * dL/dalpha = (sum s) / opacity   (a Gaussian that blends anywhere has opacity >= 1/255)
-        const float opac = a.opac[si];
         dop = opac > 0.f ? A8 / opac : 0.f;
         const float det_inv = 1.f / det;                        // the conic as the forward pass formed it (S4)
         const float cA = ec * det_inv, cB = -eb * det_inv, cC = ea * det_inv;
@@ -150,9 +180,6 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
             float bas[16], bg3[16][3];
             sh_basis<D>(dir, bas);
             sh_basis_grad<D>(dir, bg3);
-            float c[3 * K + 3];
-            if (SPLIT) load_sh_row_split<K>(a.shs, a.shs_rest, si, a.M, c);
-            else load_sh_row<K>(a.shs, si, a.M, c);
             float ddir[3] = {0.f, 0.f, 0.f};
             float *out = (SPLIT) ? nullptr : a.dL_dsh + si * (size_t)a.M * 3;
             float gch[3];
@@ -224,7 +251,7 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
             drot[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
         }
         if (RAW) {                   // chain through sigmoid / exp / normalize (scene/gaussian_model.py:33-41)
-            const float o = a.opac[si];
+            const float o = opac;
             dop *= o * (1.f - o);
             if (!a.cov3D_precomp) {
                 dscale[0] *= s[0]; dscale[1] *= s[1]; dscale[2] *= s[2];
@@ -254,8 +281,11 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
         for (int t = 0; t < 12; t++) {
             const int q = t * 64 + lane;
             const int g = (q * 43691) >> 19;         // q / 12 for q < 768
-            if ((wave_writes >> g) & 1ull) dst[q] = tile[g * SH_TILE_ROW + (q - 12 * g)];
+            if (DENSE) {                              // 64 rows of 192 B, each at its own Gaussian's place: 5.3 whole rows per store instruction
+                if (g < nrows) reinterpret_cast<float4 *>(a.dL_dsh + (size_t)rows[g] * 48)[q - 12 * g] = tile[g * SH_TILE_ROW + (q - 12 * g)];
+            } else if ((wave_writes >> g) & 1ull) dst[q] = tile[g * SH_TILE_ROW + (q - 12 * g)];
         }
+        if (DENSE) __builtin_amdgcn_wave_barrier();      // the tile is reused by the wave's next 64
     }
     if (!writes) return;
     a.dL_dmeans2D[3 * si] = dm2[0]; a.dL_dmeans2D[3 * si + 1] = dm2[1]; a.dL_dmeans2D[3 * si + 2] = 0.f;
@@ -270,6 +300,179 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
         a.dL_dscales[3 * si] = dscale[0]; a.dL_dscales[3 * si + 1] = dscale[1]; a.dL_dscales[3 * si + 2] = dscale[2];
         reinterpret_cast<float4 *>(a.dL_drots)[si] = make_float4(drot[0], drot[1], drot[2], drot[3]);
     }
+}
+
+template <int D, bool RAW, bool SPLIT>
+__global__ __launch_bounds__(256) void pergauss_bwd_kernel(PergaussBwdArgs a) {
+    extern __shared__ __align__(16) float4 sh_tile_dyn[];
+    pergauss_one<D, RAW, SPLIT, false>(a, blockIdx.x * 256 + threadIdx.x, sh_tile_dyn);
+}
+
+// Dense variant (round 3), for the reference's training layout (SH tensor with M = 16, scales + rotations).  At config 3 nine
+// Gaussians in a hundred have a gradient; a wave of the kernel above runs the whole chain (~1400 vector instructions) for its few
+// visible lanes, fetches a whole line for every few bytes it needs of them (85 MB read for 24 MB used) and writes zeros for the rest.
+// Here, while the compositing kernel runs (FP32-issue-bound, the memory system idle), gsr_backward's second stream
+//   * writes the zeros (fill_zero_kernel), and
+//   * lists the Gaussians with a gradient and copies their inputs -- mean, opacity, scale, flags, rotation, SH row: 15 x 16 bytes --
+//     into a compact buffer, 64 records per 15 KiB chunk laid out slot-major so that a wave reads its chunk with fifteen coalesced
+//     1-KiB loads (gather_visible_kernel: the scattered reads happen here, off the critical path);
+// afterwards pergauss_bwd_dense_kernel runs the chain on full waves: one wave per chunk, the only scattered reads left are the
+// accumulator rows.  List order is whatever the workgroups' atomics made it: every Gaussian is independent.
+#define GSR_PG_REC_SLOTS 15
+#define GSR_PG_GATHER_SPAN 1024
+__device__ __forceinline__ void load_record_scattered(const PergaussBwdArgs &a, const size_t g, float4 rec[GSR_PG_REC_SLOTS]) {
+    const float4 *sh4 = reinterpret_cast<const float4 *>(a.shs + g * 48);
+#pragma unroll
+    for (int v = 0; v < 12; v++) rec[3 + v] = sh4[v];
+    rec[0] = make_float4(a.means3D[3 * g], a.means3D[3 * g + 1], a.means3D[3 * g + 2], a.opac[g]);
+    rec[1] = make_float4(a.scales[3 * g], a.scales[3 * g + 1], a.scales[3 * g + 2], __uint_as_float((uint32_t)a.clamped[g]));
+    rec[2] = reinterpret_cast<const float4 *>(a.rotations)[g];
+}
+
+__global__ __launch_bounds__(256) void gather_visible_kernel(PergaussBwdArgs a) {
+    __shared__ uint32_t list[GSR_PG_GATHER_SPAN];
+    __shared__ uint32_t count, base_s;
+    if (threadIdx.x == 0) count = 0u;
+    const uint32_t mark = *a.touch_mark;
+    constexpr int PER = GSR_PG_GATHER_SPAN / 256;
+    int rad[PER];
+    uint32_t tch[PER];
+    const int g0 = blockIdx.x * GSR_PG_GATHER_SPAN + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < PER; r++) {                  // unconditional loads: a branch per load would put a memory round trip between them
+        const int g = min(g0 + 256 * r, a.P - 1);
+        rad[r] = a.radii[g];
+        tch[r] = (uint32_t)a.touched[g];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < PER; r++) {
+        const bool vis = g0 + 256 * r < a.P && rad[r] > 0 && tch[r] == mark;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(vis);
+        if (m == 0ull) continue;
+        uint32_t at = 0u;
+        if (lane == 0) at = atomicAdd(&count, (uint32_t)__builtin_popcountll(m));
+        at = __builtin_amdgcn_readfirstlane(at);
+        if (vis) list[at + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)(g0 + 256 * r);
+    }
+    __syncthreads();
+    const uint32_t n = count;
+    if (n == 0u) return;
+    if (threadIdx.x == 0) base_s = atomicAdd(a.vis_count, n);        // one device atomic per workgroup with anything to list
+    __syncthreads();
+    const uint32_t base = base_s;
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+        const uint32_t g = list[i], e = base + i;
+        a.vis_list[e] = g;
+        if (e < a.vis_cap) {
+            float4 rec[GSR_PG_REC_SLOTS];
+            load_record_scattered(a, (size_t)g, rec);
+            float4 *dst = a.vis_rec + (size_t)(e >> 6) * (64 * GSR_PG_REC_SLOTS) + (e & 63u);
+#pragma unroll
+            for (int v = 0; v < GSR_PG_REC_SLOTS; v++) dst[v * 64] = rec[v];
+        }
+    }
+}
+
+template <int D, bool RAW>
+__global__ __launch_bounds__(64) void pergauss_bwd_dense_kernel(PergaussBwdArgs a) {
+    const uint32_t count = *a.vis_count;
+    const uint32_t e0 = blockIdx.x * 64u;
+    if (e0 >= count) return;                          // wave-uniform
+    // the camera, read once into registers (scalar loads here, before anything was stored; behind the chain's load barrier the compiler
+    // would fetch each matrix again with vector loads where it is used: three more round trips)
+    float vm[16], pm[16], cp[3];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { vm[k] = a.viewmatrix[k]; pm[k] = a.projmatrix[k]; }
+    cp[0] = a.campos[0]; cp[1] = a.campos[1]; cp[2] = a.campos[2];
+    PergaussBwdArgs al = a;
+    al.viewmatrix = vm; al.projmatrix = pm; al.campos = cp;
+    __shared__ uint32_t rows[64];
+    const int lane = threadIdx.x;
+    const int nrows = (int)min(64u, count - e0);
+    const uint32_t g = a.vis_list[e0 + (uint32_t)min(lane, nrows - 1)];
+    rows[lane] = g;
+    float4 rec[GSR_PG_REC_SLOTS];
+    if (e0 + 64u <= a.vis_cap) {                      // the whole chunk was copied
+        const float4 *src = a.vis_rec + (size_t)blockIdx.x * (64 * GSR_PG_REC_SLOTS) + lane;
+#pragma unroll
+        for (int v = 0; v < GSR_PG_REC_SLOTS; v++) rec[v] = src[v * 64];
+    } else load_record_scattered(a, (size_t)g, rec);  // more Gaussians with a gradient than the buffer holds: this wave gathers its own
+    __builtin_amdgcn_wave_barrier();
+    extern __shared__ __align__(16) float4 sh_tile_dyn[];
+    pergauss_one<D, RAW, false, true>(al, (int)g, sh_tile_dyn, rows, nrows, rec);
+}
+
+// Zero-fill of all gradient outputs (the rows of the Gaussians with a gradient are overwritten afterwards): plain 16-byte stores over
+// each tensor's 16-byte-aligned body, the few floats before and after it by the first lanes of the tensor's first workgroup.
+#define GSR_FILL_SEGS 10
+#define GSR_FILL_F4_PER_BLOCK 2048          // 32 KiB per workgroup of 256 lanes: 8 stores per lane
+struct FillZeroArgs {
+    float *p[GSR_FILL_SEGS];
+    unsigned long long n[GSR_FILL_SEGS];     // floats
+    unsigned first_block[GSR_FILL_SEGS + 1]; // prefix sums of the workgroups per tensor
+    int nseg;
+};
+__global__ __launch_bounds__(256) void fill_zero_kernel(FillZeroArgs f) {
+    int sgm = 0;
+    while (sgm + 1 < f.nseg && blockIdx.x >= f.first_block[sgm + 1]) sgm++;
+    const unsigned b = blockIdx.x - f.first_block[sgm];
+    float *p = f.p[sgm];
+    const unsigned long long n = f.n[sgm];
+    const unsigned long long head = min(n, (unsigned long long)(((16u - ((uintptr_t)p & 15u)) & 15u) >> 2));   // floats before the aligned body
+    const unsigned long long body4 = (n - head) >> 2;                                                            // float4s in it
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v *q = reinterpret_cast<f4v *>(p + head);
+    const f4v z = {0.f, 0.f, 0.f, 0.f};
+    const unsigned long long at = (unsigned long long)b * GSR_FILL_F4_PER_BLOCK + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < GSR_FILL_F4_PER_BLOCK / 256; r++) {
+        const unsigned long long k = at + 256ull * r;
+        if (k < body4) __builtin_nontemporal_store(z, &q[k]);      // streamed past the L2 working set of the compositing kernel running beside it
+    }
+    if (b == 0 && threadIdx.x < 8) {
+        const unsigned long long tail0 = head + (body4 << 2);
+        if (threadIdx.x < 4) { if (threadIdx.x < head) p[threadIdx.x] = 0.f; }
+        else if (tail0 + (threadIdx.x - 4) < n) p[tail0 + (threadIdx.x - 4)] = 0.f;
+    }
+}
+
+// can the dense variant serve this call?  (the layout the records are made for)
+bool pergauss_dense_eligible(const PergaussBwdArgs &a) {
+    return a.shs && !a.shs_rest && a.M == 16 && a.scales && a.rotations && !a.cov3D_precomp && a.campos &&
+           (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.shs) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(a.rotations) & 15) == 0;
+}
+hipError_t launch_gather_visible(const PergaussBwdArgs &a, hipStream_t s) {
+    if (a.P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_visible_kernel, dim3((a.P + GSR_PG_GATHER_SPAN - 1) / GSR_PG_GATHER_SPAN), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_zero(const PergaussBwdArgs &a, hipStream_t s) {
+    if (a.P <= 0) return hipSuccess;
+    FillZeroArgs f;
+    f.nseg = 0;
+    unsigned blocks = 0;
+    const unsigned long long P = (unsigned long long)a.P;
+    auto add = [&](float *p, unsigned long long n) {
+        if (!p || n == 0 || f.nseg >= GSR_FILL_SEGS) return;
+        f.p[f.nseg] = p; f.n[f.nseg] = n; f.first_block[f.nseg] = blocks;
+        blocks += (unsigned)((n / 4 + GSR_FILL_F4_PER_BLOCK - 1) / GSR_FILL_F4_PER_BLOCK) + (n / 4 == 0 ? 1u : 0u);
+        f.nseg++;
+    };
+    const bool split = a.shs_rest != nullptr;
+    add(a.dL_dmeans2D, 3 * P); add(a.dL_dopacity, P); add(a.dL_dcolors, 3 * P); add(a.dL_dmeans3D, 3 * P); add(a.dL_dcov3D, 6 * P);
+    if (a.shs) {
+        if (split) { add(a.dL_dsh, 3 * P); add(a.dL_dsh_rest, 3 * P * (unsigned long long)(a.M - 1)); }
+        else add(a.dL_dsh, 3 * P * (unsigned long long)a.M);
+    }
+    if (a.dL_dscales) { add(a.dL_dscales, 3 * P); add(a.dL_drots, 4 * P); }
+    f.first_block[f.nseg] = blocks;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_zero_kernel, dim3(blocks), dim3(256), 0, s, f);
+    return hipGetLastError();
 }
 
 hipError_t launch_pergauss_bwd(const PergaussBwdArgs &a_in, hipStream_t s) {
@@ -295,6 +498,21 @@ hipError_t launch_pergauss_bwd(const PergaussBwdArgs &a_in, hipStream_t s) {
             if (e != hipSuccess) return e;
             attr_set.fetch_or(1ull << (dev & 63));
         }
+    }
+    if (a.dense) {                                    // gsr_backward checked: SH tensor with M = 16, scales + rotations, not split
+        const dim3 dgrid((a.P + 63) / 64), dblock(64);
+        const size_t dlds = lds / 4;                 // one wave's tile
+        switch (d * 2 + (raw ? 1 : 0)) {
+            case 0: hipLaunchKernelGGL((pergauss_bwd_dense_kernel<0, false>), dgrid, dblock, dlds, s, a); break;
+            case 1: hipLaunchKernelGGL((pergauss_bwd_dense_kernel<0, true>), dgrid, dblock, dlds, s, a); break;
+            case 2: hipLaunchKernelGGL((pergauss_bwd_dense_kernel<1, false>), dgrid, dblock, dlds, s, a); break;
+            case 3: hipLaunchKernelGGL((pergauss_bwd_dense_kernel<1, true>), dgrid, dblock, dlds, s, a); break;
+            case 4: hipLaunchKernelGGL((pergauss_bwd_dense_kernel<2, false>), dgrid, dblock, dlds, s, a); break;
+            case 5: hipLaunchKernelGGL((pergauss_bwd_dense_kernel<2, true>), dgrid, dblock, dlds, s, a); break;
+            case 6: hipLaunchKernelGGL((pergauss_bwd_dense_kernel<3, false>), dgrid, dblock, dlds, s, a); break;
+            default: hipLaunchKernelGGL((pergauss_bwd_dense_kernel<3, true>), dgrid, dblock, dlds, s, a); break;
+        }
+        return hipGetLastError();
     }
 #define GSR_LAUNCH(DD)                                                                                   \
     do {                                                                                                 \
