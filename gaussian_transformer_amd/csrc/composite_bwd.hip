@@ -72,7 +72,208 @@ struct BwdTally { unsigned long long staged = 0, visits = 0, blocks = 0, ok = 0,
 // One work unit: the entries [lo, hi) of the list of `tile`, against the NPX blocks `sub` names.  hi < 0: up to the last contributor
 // of these pixels (the whole half tile, the classic decomposition).  ckslot != ~0: pixels that blended anything at or behind entry
 // hi start from the forward pass's checkpoint at that boundary instead of from the end of their list (SegView, gsr_internal.h).
-template <int NPX, int COUNT, bool DET>
+// ---- the reverse walk of one staged batch, 2 blocks per wave, written out (round 3; see composite_fwd.hip::walk_batch_2blocks) ----
+// Same arithmetic, operand order and fma contraction as the C++ walk below (what clang makes of it was the model), but: which entries
+// reach which block (and lie in front of the block's last contributor) is a lane mask per block made at staging time -- no
+// v_readfirstlane, no per-visit comparisons against blk_last; the first block of a visit writes the nine sums, the second adds to
+// them (no zero fill, no duplicated products); the reduction rows are written with immediate offsets; the totals leave through
+// global_atomic_add_f32 with the accumulator base in SGPRs and a 32-bit byte offset (rows < 2^26: gsr_backward checks).
+// v36..v63 are used by name: record v36-45 (px py a b | c opacity r g | blue, bits|row<<4), the nine sums v46-54, dy u w v55-57,
+// temporaries v58-63; the reduction reads its 16 floats into v36-43 and v56-63.
+struct BwdPx { float T, accd, fx, d0, d1, d2, tb; int last; };
+__device__ __forceinline__ void walk_batch_bwd_2blocks(uint32_t lds, uint32_t redw, uint32_t redr, uint32_t lane, int base, float fy,
+                                                       unsigned long long m, unsigned long long b0m, unsigned long long b1m,
+                                                       const float *acc, BwdPx &p0, BwdPx &p1) {
+    uint32_t j, pos;
+    unsigned long long m1, m3, any;
+    const unsigned long long redm = 0xFFFFFFFFFull, slotm = 0x111111111ull;
+    asm volatile(
+        "1:\n"
+        "s_flbit_i32_b64 %[j], %[m]\n"
+        "s_xor_b32 %[j], %[j], 63\n"                  // highest set bit: the batch is walked back to front
+        "s_bitset0_b64 %[m], %[j]\n"
+        "v_lshl_add_u32 v58, %[j], 4, %[lds]\n"
+        "v_lshl_add_u32 v59, %[j], 3, %[lds]\n"
+        "ds_read_b128 v[36:39], v58\n"                // px, py, a, b
+        "ds_read_b128 v[40:43], v58 offset:1024\n"    // c, opacity, red, green
+        "ds_read_b64 v[44:45], v59 offset:2048\n"     // blue, reachability bits | accumulator row << 4
+        "s_add_i32 %[pos], %[j], %[base]\n"
+        "s_waitcnt lgkmcnt(2)\n"
+        "v_sub_f32 v55, v37, %[fy]\n"                 // dy
+        "v_mul_f32 v56, v55, v39\n"                   // u = b dy
+        "s_waitcnt lgkmcnt(1)\n"
+        "v_mul_f32 v57, v55, v40\n"
+        "v_mul_f32 v57, v55, v57\n"                   // w = (c dy) dy
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_bitcmp1_b64 %[b0m], %[j]\n"
+        "s_cbranch_scc0 3f\n"
+        "v_sub_f32 v58, v36, %[fx0]\n"
+        "v_fma_f32 v59, v38, v58, v56\n"
+        "v_fma_f32 v59, v59, v58, v57\n"
+        "v_exp_f32 v60, v59\n"
+        "v_cmp_nlt_f32_e64 %[m1], 0, v59\n"
+        "v_cmp_lt_i32 vcc, %[pos], %[l0]\n"
+        "v_mul_f32 v61, %[d01], v43\n"
+        "v_mul_f32 v60, v41, v60\n"
+        "v_cmp_ngt_f32_e64 %[m3], %[amin], v60\n"
+        "s_and_b64 %[m3], %[m3], %[m1]\n"
+        "s_and_b64 vcc, %[m3], vcc\n"
+        "v_cndmask_b32 v60, 0, v60, vcc\n"
+        "v_min_f32 v62, 0x3f7d70a4, v60\n"
+        "v_sub_f32 v63, 1.0, v62\n"
+        "v_rcp_f32 v63, v63\n"
+        "v_fmac_f32 v61, %[d00], v42\n"
+        "v_fmac_f32 v61, %[d02], v44\n"
+        "v_sub_f32 v61, v61, %[A0]\n"
+        "v_fma_f32 v59, %[T0], v61, -%[tb0]\n"
+        "v_mul_f32 %[T0], %[T0], v63\n"
+        "v_mul_f32 v59, v59, v63\n"
+        "v_fmac_f32 %[A0], v61, v62\n"
+        "v_mul_f32 v62, v62, %[T0]\n"
+        "s_mov_b64 %[any], vcc\n"
+        "v_mul_f32 v46, %[d00], v62\n"
+        "v_mul_f32 v47, %[d01], v62\n"
+        "v_mul_f32 v48, %[d02], v62\n"
+        "v_mul_f32 v54, v60, v59\n"
+        "v_mul_f32 v49, v58, v54\n"
+        "v_mul_f32 v50, v55, v54\n"
+        "v_mul_f32 v51, v58, v49\n"
+        "v_mul_f32 v52, v55, v49\n"
+        "v_mul_f32 v53, v55, v50\n"
+        "s_bitcmp1_b64 %[b1m], %[j]\n"
+        "s_cbranch_scc0 4f\n"
+        "v_sub_f32 v58, v36, %[fx1]\n"
+        "v_fma_f32 v59, v38, v58, v56\n"
+        "v_fma_f32 v59, v59, v58, v57\n"
+        "v_exp_f32 v60, v59\n"
+        "v_cmp_nlt_f32_e64 %[m1], 0, v59\n"
+        "v_cmp_lt_i32 vcc, %[pos], %[l1]\n"
+        "v_mul_f32 v61, %[d11], v43\n"
+        "v_mul_f32 v60, v41, v60\n"
+        "v_cmp_ngt_f32_e64 %[m3], %[amin], v60\n"
+        "s_and_b64 %[m3], %[m3], %[m1]\n"
+        "s_and_b64 vcc, %[m3], vcc\n"
+        "v_cndmask_b32 v60, 0, v60, vcc\n"
+        "v_min_f32 v62, 0x3f7d70a4, v60\n"
+        "v_sub_f32 v63, 1.0, v62\n"
+        "v_rcp_f32 v63, v63\n"
+        "v_fmac_f32 v61, %[d10], v42\n"
+        "v_fmac_f32 v61, %[d12], v44\n"
+        "v_sub_f32 v61, v61, %[A1]\n"
+        "v_fma_f32 v59, %[T1], v61, -%[tb1]\n"
+        "v_mul_f32 %[T1], %[T1], v63\n"
+        "v_mul_f32 v59, v59, v63\n"
+        "v_fmac_f32 %[A1], v61, v62\n"
+        "v_mul_f32 v62, v62, %[T1]\n"
+        "s_or_b64 %[any], %[any], vcc\n"
+        "v_fmac_f32 v46, %[d10], v62\n"
+        "v_fmac_f32 v47, %[d11], v62\n"
+        "v_fmac_f32 v48, %[d12], v62\n"
+        "v_mul_f32 v61, v60, v59\n"
+        "v_fmac_f32 v54, v60, v59\n"
+        "v_mul_f32 v60, v58, v61\n"
+        "v_mul_f32 v59, v55, v61\n"
+        "v_fmac_f32 v49, v58, v61\n"
+        "v_fmac_f32 v50, v55, v61\n"
+        "v_fmac_f32 v51, v58, v60\n"
+        "v_fmac_f32 v52, v55, v60\n"
+        "v_fmac_f32 v53, v55, v59\n"
+        "s_branch 4f\n"
+        "3:\n"                                        // block 0 takes no part: block 1 does (the entry is in one of the masks)
+        "v_sub_f32 v58, v36, %[fx1]\n"
+        "v_fma_f32 v59, v38, v58, v56\n"
+        "v_fma_f32 v59, v59, v58, v57\n"
+        "v_exp_f32 v60, v59\n"
+        "v_cmp_nlt_f32_e64 %[m1], 0, v59\n"
+        "v_cmp_lt_i32 vcc, %[pos], %[l1]\n"
+        "v_mul_f32 v61, %[d11], v43\n"
+        "v_mul_f32 v60, v41, v60\n"
+        "v_cmp_ngt_f32_e64 %[m3], %[amin], v60\n"
+        "s_and_b64 %[m3], %[m3], %[m1]\n"
+        "s_and_b64 vcc, %[m3], vcc\n"
+        "v_cndmask_b32 v60, 0, v60, vcc\n"
+        "v_min_f32 v62, 0x3f7d70a4, v60\n"
+        "v_sub_f32 v63, 1.0, v62\n"
+        "v_rcp_f32 v63, v63\n"
+        "v_fmac_f32 v61, %[d10], v42\n"
+        "v_fmac_f32 v61, %[d12], v44\n"
+        "v_sub_f32 v61, v61, %[A1]\n"
+        "v_fma_f32 v59, %[T1], v61, -%[tb1]\n"
+        "v_mul_f32 %[T1], %[T1], v63\n"
+        "v_mul_f32 v59, v59, v63\n"
+        "v_fmac_f32 %[A1], v61, v62\n"
+        "v_mul_f32 v62, v62, %[T1]\n"
+        "s_mov_b64 %[any], vcc\n"
+        "v_mul_f32 v46, %[d10], v62\n"
+        "v_mul_f32 v47, %[d11], v62\n"
+        "v_mul_f32 v48, %[d12], v62\n"
+        "v_mul_f32 v54, v60, v59\n"
+        "v_mul_f32 v49, v58, v54\n"
+        "v_mul_f32 v50, v55, v54\n"
+        "v_mul_f32 v51, v58, v49\n"
+        "v_mul_f32 v52, v55, v49\n"
+        "v_mul_f32 v53, v55, v50\n"
+        "4:\n"
+        "s_cmp_eq_u64 %[any], 0\n"
+        "s_cbranch_scc1 5f\n"                         // no pixel of this wave blends the splat
+        // reduction through LDS: nine rows of the lanes' partial sums, 36 lanes add 16 floats each, two DPP steps, one 9-lane atomic
+        "ds_write_b32 %[redw], v46\n"
+        "ds_write_b32 %[redw], v47 offset:272\n"
+        "ds_write_b32 %[redw], v48 offset:544\n"
+        "ds_write_b32 %[redw], v49 offset:816\n"
+        "ds_write_b32 %[redw], v50 offset:1088\n"
+        "ds_write_b32 %[redw], v51 offset:1360\n"
+        "ds_write_b32 %[redw], v52 offset:1632\n"
+        "ds_write_b32 %[redw], v53 offset:1904\n"
+        "ds_write_b32 %[redw], v54 offset:2176\n"
+        "s_mov_b64 exec, %[redm]\n"
+        "ds_read_b128 v[36:39], %[redr]\n"
+        "ds_read_b128 v[40:43], %[redr] offset:16\n"
+        "ds_read_b128 v[56:59], %[redr] offset:32\n"
+        "ds_read_b128 v[60:63], %[redr] offset:48\n"
+        "s_waitcnt lgkmcnt(3)\n"
+        "v_add_f32 v36, v36, v37\n"
+        "v_add_f32 v37, v38, v39\n"
+        "v_add_f32 v36, v36, v37\n"
+        "s_waitcnt lgkmcnt(2)\n"
+        "v_add_f32 v37, v40, v41\n"
+        "v_add_f32 v38, v42, v43\n"
+        "v_add_f32 v37, v37, v38\n"
+        "v_add_f32 v36, v36, v37\n"
+        "s_waitcnt lgkmcnt(1)\n"
+        "v_add_f32 v37, v56, v57\n"
+        "v_add_f32 v38, v58, v59\n"
+        "v_add_f32 v37, v37, v38\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_add_f32 v38, v60, v61\n"
+        "v_add_f32 v39, v62, v63\n"
+        "v_add_f32 v38, v38, v39\n"
+        "v_add_f32 v37, v37, v38\n"
+        "v_add_f32 v36, v36, v37\n"
+        "s_mov_b64 exec, -1\n"
+        "s_nop 1\n"                                   // a DPP read of a VGPR two wait states after its write
+        "v_add_f32_dpp v36, v36, v36 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "s_nop 1\n"
+        "v_add_f32_dpp v36, v36, v36 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "s_mov_b64 exec, %[slotm]\n"                  // lanes 0, 4, ..., 32 hold the nine totals
+        "v_and_b32 v37, -16, v45\n"
+        "v_lshl_add_u32 v37, v37, 2, %[lane]\n"       // 64 row + 4 value
+        "global_atomic_add_f32 v37, v36, %[acc]\n"
+        "s_mov_b64 exec, -1\n"
+        "5:\n"
+        "s_cmp_lg_u64 %[m], 0\n"
+        "s_cbranch_scc1 1b\n"
+        : [m] "+s"(m), [j] "=&s"(j), [pos] "=&s"(pos), [m1] "=&s"(m1), [m3] "=&s"(m3), [any] "=&s"(any),
+          [T0] "+v"(p0.T), [A0] "+v"(p0.accd), [T1] "+v"(p1.T), [A1] "+v"(p1.accd)
+        : [b0m] "s"(b0m), [b1m] "s"(b1m), [base] "s"(base), [amin] "s"(GSR_ALPHA_MIN), [redm] "s"(redm), [slotm] "s"(slotm), [acc] "s"(acc),
+          [lds] "v"(lds), [redw] "v"(redw), [redr] "v"(redr), [lane] "v"(lane), [fy] "v"(fy),
+          [fx0] "v"(p0.fx), [d00] "v"(p0.d0), [d01] "v"(p0.d1), [d02] "v"(p0.d2), [tb0] "v"(p0.tb), [l0] "v"(p0.last),
+          [fx1] "v"(p1.fx), [d10] "v"(p1.d0), [d11] "v"(p1.d1), [d12] "v"(p1.d2), [tb1] "v"(p1.tb), [l1] "v"(p1.last)
+        : "memory", "scc", "vcc", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49",
+          "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+}
+
+template <int NPX, int COUNT, bool DET, bool ASMW = false>
 __device__ __forceinline__ void bwd_unit(const CompositeBwdArgs &a, float4 *my, const int lane, const int tile, const int sub, const int lo,
                                          int hi, const uint32_t ckslot, BwdTally &tl) {
     constexpr int UNITS_PER_TILE = 4 / NPX;          // waves per tile
@@ -144,6 +345,7 @@ __device__ __forceinline__ void bwd_unit(const CompositeBwdArgs &a, float4 *my, 
         const int cnt = min(64, hi - base);
         __builtin_amdgcn_wave_barrier();
         bool live = false;
+        uint32_t mybits = 0u;                         // blocks of this wave the lane's entry can reach
         if (lane < cnt && GSR_IDX_OK((size_t)range.x + base + lane, a.contrib_stride, a.seg.hdr + GSR_DBG_SEG_WORD, GSR_BOUND_BWD_LIST_READ)) {
             const uint32_t g = a.point_list[range.x + base + lane];
             const float4 r0 = rec4[3 * (size_t)g], r1 = rec4[3 * (size_t)g + 1], r2 = rec4[3 * (size_t)g + 2];
@@ -155,6 +357,7 @@ __device__ __forceinline__ void bwd_unit(const CompositeBwdArgs &a, float4 *my, 
                 bits |= a.contrib[(size_t)blk * a.contrib_stride + range.x + base + lane] ? (1u << q) : 0u;
             }
             live = bits != 0u;
+            mybits = bits;
             const StagedConic sc = stage_conic(r0.z, r0.w, r1.x);       // as the forward pass staged it
             my[lane] = make_float4(r0.x, r0.y, sc.a, sc.b);
             my[64 + lane] = make_float4(sc.c, r1.y, r1.z, r1.w);
@@ -166,6 +369,21 @@ __device__ __forceinline__ void bwd_unit(const CompositeBwdArgs &a, float4 *my, 
         uint64_t todo = __ballot(live);
         if (COUNT) { tl.staged += cnt; tl.visits += __builtin_popcountll(todo); }
         __builtin_amdgcn_wave_barrier();
+        if constexpr (ASMW) {
+            static_assert(NPX == 2 && COUNT == 0 && !DET, "the written-out walk exists for 2 blocks per wave, uninstrumented, atomic sums");
+            // entries that reach block q and lie in front of its last contributor (positions base .. blk_last[q] - 1), as lane masks
+            auto below = [](int n) { return n >= 64 ? ~0ull : (n <= 0 ? 0ull : (1ull << n) - 1ull); };
+            const unsigned long long b0m = __builtin_amdgcn_ballot_w64((mybits & 1u) != 0u) & below(blk_last[0] - base);
+            const unsigned long long b1m = __builtin_amdgcn_ballot_w64((mybits & 2u) != 0u) & below(blk_last[1] - base);
+            const unsigned long long m = b0m | b1m;
+            if (m != 0ull) {
+                BwdPx p0 = {Tr[0], accd[0], fx[0], d0[0], d1[0], d2[0], tb[0], last[0]}, p1 = {Tr[1], accd[1], fx[1], d0[1], d1[1], d2[1], tb[1], last[1]};
+                walk_batch_bwd_2blocks((uint32_t)(uintptr_t)my, (uint32_t)(uintptr_t)(red + lane), (uint32_t)(uintptr_t)red_rd, (uint32_t)lane, base,
+                                       fy[0], m, b0m, b1m, a.acc, p0, p1);
+                Tr[0] = p0.T; accd[0] = p0.accd; Tr[1] = p1.T; accd[1] = p1.accd;
+            }
+            todo = 0;
+        }
         // The splats of the batch are visited back to front.  (Issuing the next record's LDS reads a visit ahead was measured:
         // no gain here, 10 % slower in the forward kernel -- the waves of a SIMD already cover that latency for each other.)
         auto visit = [&](const float4 r0, const float4 r1, const float4 r2, const int j) __attribute__((always_inline)) {
@@ -277,8 +495,8 @@ __device__ __forceinline__ void bwd_flush_tally(const CompositeBwdArgs &a, const
 }
 
 // classic decomposition: one wave per NPX blocks of a tile, XCD-banded
-template <int NPX, int COUNT, bool DET>
-__global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, int nblocks_padded, int /*exact_cull*/) {
+template <int NPX, int COUNT, bool DET, bool ASMW>
+__device__ __forceinline__ void bwd_kernel_body(const CompositeBwdArgs &a, int nblocks_padded) {
     constexpr int UNITS_PER_TILE = 4 / NPX;          // waves per tile
     extern __shared__ __align__(16) float4 stage_dyn[];     // per wave: 64 records x 3 float4, then 9 x RED_STRIDE floats of reduction scratch
     const int T = a.gridx * a.gridy;
@@ -288,8 +506,16 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, 
     if (tile >= T) return;                            // wave-uniform
     const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
     BwdTally tl;
-    bwd_unit<NPX, COUNT, DET>(a, stage_dyn + wave * BWD_LDS_F4, lane, tile, sub, 0, -1, ~0u, tl);
+    bwd_unit<NPX, COUNT, DET, ASMW>(a, stage_dyn + wave * BWD_LDS_F4, lane, tile, sub, 0, -1, ~0u, tl);
     bwd_flush_tally<COUNT>(a, tl, lane, (unsigned)unit, t_start);
+}
+template <int NPX, int COUNT, bool DET>
+__global__ __launch_bounds__(256) void composite_bwd_kernel(CompositeBwdArgs a, int nblocks_padded, int /*exact_cull*/) {
+    bwd_kernel_body<NPX, COUNT, DET, false>(a, nblocks_padded);
+}
+// the default instantiation: written-out walk (8 waves per SIMD asked for explicitly: the walk names 28 registers)
+__global__ __launch_bounds__(256, 8) void composite_bwd_walk_kernel(CompositeBwdArgs a, int nblocks_padded, int /*exact_cull*/) {
+    bwd_kernel_body<2, 0, false, true>(a, nblocks_padded);
 }
 
 // One zero-fill unit (FillArgs): the gradient rows of the Gaussians [g0, g1) that pergauss_bwd.hip will not write -- culled, or not
@@ -356,8 +582,8 @@ __device__ __forceinline__ void fill_unit(const FillArgs &f, const int lane, con
 // XCD band of tiles in order of decreasing length by plan_units() below -- from the band's ticket counter; a wave whose band is
 // finished helps the next band.  Long chains start first, the short units fill the end of the kernel; neighbouring tiles stay on one
 // XCD (their splat records share its L2) as long as that XCD has work of its own.
-template <int COUNT, bool DET>
-__global__ __launch_bounds__(64) void composite_bwd_pk_kernel(CompositeBwdArgs a) {
+template <int COUNT, bool DET, bool ASMW>
+__device__ __forceinline__ void bwd_pk_body(const CompositeBwdArgs &a) {
     extern __shared__ __align__(16) float4 stage_dyn[];
     const int lane = threadIdx.x;
     uint32_t *hdr = a.seg.hdr;
@@ -397,8 +623,8 @@ __global__ __launch_bounds__(64) void composite_bwd_pk_kernel(CompositeBwdArgs a
         u.x = __builtin_amdgcn_readfirstlane(u.x); u.y = __builtin_amdgcn_readfirstlane(u.y);
         u.z = __builtin_amdgcn_readfirstlane(u.z); u.w = __builtin_amdgcn_readfirstlane(u.w);
         BwdTally tl;
-        if (u.x == ~0u) fill_unit(a.fill, lane, (int)u.y, (int)u.z);       // wave-uniform
-        else bwd_unit<2, COUNT, DET>(a, stage_dyn, lane, (int)(u.x >> 1), (int)(u.x & 1u), (int)u.y, (int)u.z, u.w, tl);
+        if (!ASMW && u.x == ~0u) fill_unit(a.fill, lane, (int)u.y, (int)u.z);       // wave-uniform (the walk variant is launched without fill units)
+        else bwd_unit<2, COUNT, DET, ASMW>(a, stage_dyn, lane, (int)(u.x >> 1), (int)(u.x & 1u), (int)u.y, (int)u.z, u.w, tl);
         bwd_flush_tally<COUNT>(a, tl, lane, (unsigned)at, t_start);
         // the next ticket is drawn only now: a ticket drawn ahead of time is a unit nobody else can take while this wave is still busy --
         // measured: once all tickets were handed out, half the waves left and the rest worked off two units each
@@ -406,6 +632,14 @@ __global__ __launch_bounds__(64) void composite_bwd_pk_kernel(CompositeBwdArgs a
         if (lane == 0) nxt = atomicAdd(&hdr[SEG_BTICKET + GSR_SEG_CTR_STRIDE * band], 1u);
         ticket = __builtin_amdgcn_readfirstlane(nxt);
     }
+}
+
+template <int COUNT, bool DET>
+__global__ __launch_bounds__(64) void composite_bwd_pk_kernel(CompositeBwdArgs a) {
+    bwd_pk_body<COUNT, DET, false>(a);
+}
+__global__ __launch_bounds__(64, 8) void composite_bwd_pk_walk_kernel(CompositeBwdArgs a) {     // the default: written-out walk
+    bwd_pk_body<0, false, true>(a);
 }
 
 // The unit list of one band (one workgroup of 256 threads): every half tile's pieces -- [k seg, (k+1) seg) below each checkpoint the
@@ -584,6 +818,8 @@ static hipError_t launch_bwd(const CompositeBwdArgs &a, int exact_cull, int wpb,
         hipLaunchKernelGGL((composite_bwd_kernel<NPX, 2, false>), dim3(padded), dim3(64 * wpb), lds, s, a, padded, exact_cull);
     else if (a.counters)
         hipLaunchKernelGGL((composite_bwd_kernel<NPX, 1, false>), dim3(padded), dim3(64 * wpb), lds, s, a, padded, exact_cull);
+    else if (NPX == 2 && a.asm_walk)
+        hipLaunchKernelGGL(composite_bwd_walk_kernel, dim3(padded), dim3(64 * wpb), lds, s, a, padded, exact_cull);
     else
         hipLaunchKernelGGL((composite_bwd_kernel<NPX, 0, false>), dim3(padded), dim3(64 * wpb), lds, s, a, padded, exact_cull);
     return hipGetLastError();
@@ -634,12 +870,13 @@ static int resident_waves(K kernel, size_t lds, std::atomic<int> &cache) {
 }
 static size_t pk_lds_bytes() { return (size_t)BWD_LDS_F4 * sizeof(float4) + (size_t)g_composite_lds_pad; }
 
-int composite_bwd_persistent_grid(int T, int det, int count_mode) {
-    static std::atomic<int> c_plain{0}, c_det{0}, c_cnt{0}, c_trace{0};
+int composite_bwd_persistent_grid(int T, int det, int count_mode, int asm_walk) {
+    static std::atomic<int> c_plain{0}, c_det{0}, c_cnt{0}, c_trace{0}, c_walk{0};
     int n;
     if (det) n = resident_waves(composite_bwd_pk_kernel<0, true>, pk_lds_bytes(), c_det);
     else if (count_mode == 2) n = resident_waves(composite_bwd_pk_kernel<2, false>, pk_lds_bytes(), c_trace);
     else if (count_mode == 1) n = resident_waves(composite_bwd_pk_kernel<1, false>, pk_lds_bytes(), c_cnt);
+    else if (asm_walk) n = resident_waves(composite_bwd_pk_walk_kernel, pk_lds_bytes(), c_walk);
     else n = resident_waves(composite_bwd_pk_kernel<0, false>, pk_lds_bytes(), c_plain);
     long long most = 2ll * T * (1 + GSR_SEG_MAXCK);              // units a frame can have at all
     most = (most + GSR_SEG_BANDS - 1) / GSR_SEG_BANDS * GSR_SEG_BANDS;     // a multiple of the bands: wave b starts in band b & 7
@@ -656,6 +893,8 @@ hipError_t launch_composite_bwd_persistent(const CompositeBwdArgs &a, int grid, 
         hipLaunchKernelGGL((composite_bwd_pk_kernel<2, false>), dim3(grid), dim3(64), lds, s, a);
     else if (a.counters)
         hipLaunchKernelGGL((composite_bwd_pk_kernel<1, false>), dim3(grid), dim3(64), lds, s, a);
+    else if (a.asm_walk && a.fill.chunk == 0)
+        hipLaunchKernelGGL(composite_bwd_pk_walk_kernel, dim3(grid), dim3(64), lds, s, a);
     else
         hipLaunchKernelGGL((composite_bwd_pk_kernel<0, false>), dim3(grid), dim3(64), lds, s, a);
     return hipGetLastError();

@@ -716,7 +716,9 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     const int gridx = grid_dim(W), gridy = grid_dim(H);
     const bool persistent = sp.persistent_bwd && R > 0;
     const SegView &segv = im.seg;
-    const int pk_grid = persistent ? composite_bwd_persistent_grid(gridx * gridy, det ? 1 : 0, lane_counters(1) ? g_count_lanes.load() : 0) : 0;
+    // the written-out reverse walk addresses the accumulator rows with a 32-bit byte offset: rows < 2^26
+    const int bwd_asm = g_asm_walk.load() && !det && !lane_counters(1) && acc_rows(P) < (1u << 26) ? 1 : 0;
+    const int pk_grid = persistent ? composite_bwd_persistent_grid(gridx * gridy, det ? 1 : 0, lane_counters(1) ? g_count_lanes.load() : 0, bwd_asm) : 0;
     const int fill_chunk = persistent && g_fill_in_tail.load() ? seg_fill_chunk(P) : 0;       // zero-fill units in the persistent kernel's lists
 
     PergaussBwdArgs pa;
@@ -771,6 +773,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
         ca.det = det ? (float *)((char *)bwd_ws + align_up(acc_bytes)) : nullptr;
         ca.P = P; ca.rect = g.rect; ca.tiles = g.tiles; ca.depth_bits = reinterpret_cast<const uint32_t *>(g.depth);
         ca.seg = segv;
+        ca.asm_walk = bwd_asm;
         ca.fill.P = P; ca.fill.M = M; ca.fill.chunk = fill_chunk; ca.fill.radii = radii; ca.fill.touched = g.touched; ca.fill.mark = g.touch_mark;
         ca.fill.means2D = dL_dmeans2D; ca.fill.opacity = dL_dopacity; ca.fill.colors = dL_dcolors; ca.fill.means3D = dL_dmeans3D;
         ca.fill.cov3D = dL_dcov3D; ca.fill.sh = shs ? dL_dsh : nullptr; ca.fill.sh_rest = shs_rest ? dL_dsh_rest : nullptr;

@@ -341,12 +341,13 @@ struct CompositeBwdArgs {
     const uint32_t *depth_bits;
     SegView seg;             // the forward pass's checkpoints and work units (persistent kernel)
     FillArgs fill;           // persistent kernel only
+    int asm_walk;            // 1: the written-out walk (composite_bwd.hip::walk_batch_bwd_2blocks) where it exists; needs acc rows < 2^26
 };
 hipError_t launch_composite_bwd(const CompositeBwdArgs &a, int npx, int exact_cull, int waves_per_block, hipStream_t s);
 hipError_t launch_bound_selftest(uint32_t *words, hipStream_t s);
 // persistent reverse kernel (2 blocks per wave): `grid` waves draw the units the forward pass filed; the ticket counter must hold `grid`
 hipError_t launch_composite_bwd_persistent(const CompositeBwdArgs &a, int grid, hipStream_t s);
-int composite_bwd_persistent_grid(int T, int det, int count_mode);
+int composite_bwd_persistent_grid(int T, int det, int count_mode, int asm_walk);
 // clears the accumulator rows the reverse pass can add into; with plan_grid > 0 its first GSR_SEG_BANDS workgroups also build the
 // persistent reverse kernel's unit lists from what the forward pass left in `seg` and set the ticket counters for `plan_grid` waves
 hipError_t launch_zero_marked_rows(int P, const uint8_t *touched, const uint32_t *mark, float *acc, size_t rows_total, const SegView &seg,
