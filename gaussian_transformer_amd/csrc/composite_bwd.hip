@@ -73,13 +73,17 @@ struct BwdTally { unsigned long long staged = 0, visits = 0, blocks = 0, ok = 0,
 // of these pixels (the whole half tile, the classic decomposition).  ckslot != ~0: pixels that blended anything at or behind entry
 // hi start from the forward pass's checkpoint at that boundary instead of from the end of their list (SegView, gsr_internal.h).
 // ---- the reverse walk of one staged batch, 2 blocks per wave, written out (round 3; see composite_fwd.hip::walk_batch_2blocks) ----
-// Same arithmetic, operand order and fma contraction as the C++ walk below (what clang makes of it was the model), but: which entries
-// reach which block (and lie in front of the block's last contributor) is a lane mask per block made at staging time -- no
-// v_readfirstlane, no per-visit comparisons against blk_last; the first block of a visit writes the nine sums, the second adds to
-// them (no zero fill, no duplicated products); the reduction rows are written with immediate offsets; the totals leave through
-// global_atomic_add_f32 with the accumulator base in SGPRs and a 32-bit byte offset (rows < 2^26: gsr_backward checks).
-// v36..v63 are used by name: record v36-45 (px py a b | c opacity r g | blue, bits|row<<4), the nine sums v46-54, dy u w v55-57,
-// temporaries v58-63; the reduction reads its 16 floats into v36-43 and v56-63.
+// The decisions (power, alpha, the tests on them) are formed exactly as in the C++ walk below and in the forward pass; the sums are
+// not bit-identical to the C++ walk's (packed multiply-adds for the moments, a differently associated 16-float tree), within the
+// order-of-addition tolerance the atomics impose anyway.  What differs in structure: which entries reach which block (and lie in
+// front of the block's last contributor) is a lane mask per block made at staging time -- no v_readfirstlane, no per-visit
+// comparisons against blk_last; the first block of a visit writes the nine sums, the second adds to them (no zero fill, no
+// duplicated products); the moments s (dx, dy), s dx (dx, dy) are v_pk_mul/fma_f32 on the register pair (dx, dy); the reduction rows
+// are written with immediate offsets and folded with v_pk_add_f32; the totals leave through global_atomic_add_f32 with the
+// accumulator base in SGPRs and a 32-bit byte offset (rows < 2^26: gsr_backward checks).
+// v36..v63 are used by name: record v36-45 (px py a b | c opacity r g | blue, bits|row<<4); sums v46-48 (colour), v[50:51] (s dx,
+// s dy), v[52:53] (s dx dx, s dx dy), v49 (s dy dy), v54 (s); u w v56-57, (dx, dy) v[58:59], temporaries v55, v60-63; the reduction
+// reads its 16 floats into v36-43 and v56-63.
 struct BwdPx { float T, accd, fx, d0, d1, d2, tb; int last; };
 __device__ __forceinline__ void walk_batch_bwd_2blocks(uint32_t lds, uint32_t redw, uint32_t redr, uint32_t lane, int base, float fy,
                                                        unsigned long long m, unsigned long long b0m, unsigned long long b1m,
@@ -99,19 +103,19 @@ __device__ __forceinline__ void walk_batch_bwd_2blocks(uint32_t lds, uint32_t re
         "ds_read_b64 v[44:45], v59 offset:2048\n"     // blue, reachability bits | accumulator row << 4
         "s_add_i32 %[pos], %[j], %[base]\n"
         "s_waitcnt lgkmcnt(2)\n"
-        "v_sub_f32 v55, v37, %[fy]\n"                 // dy
-        "v_mul_f32 v56, v55, v39\n"                   // u = b dy
+        "v_sub_f32 v59, v37, %[fy]\n"                 // dy
+        "v_mul_f32 v56, v59, v39\n"                   // u = b dy
         "s_waitcnt lgkmcnt(1)\n"
-        "v_mul_f32 v57, v55, v40\n"
-        "v_mul_f32 v57, v55, v57\n"                   // w = (c dy) dy
+        "v_mul_f32 v57, v59, v40\n"
+        "v_mul_f32 v57, v59, v57\n"                   // w = (c dy) dy
         "s_waitcnt lgkmcnt(0)\n"
         "s_bitcmp1_b64 %[b0m], %[j]\n"
         "s_cbranch_scc0 3f\n"
         "v_sub_f32 v58, v36, %[fx0]\n"
-        "v_fma_f32 v59, v38, v58, v56\n"
-        "v_fma_f32 v59, v59, v58, v57\n"
-        "v_exp_f32 v60, v59\n"
-        "v_cmp_nlt_f32_e64 %[m1], 0, v59\n"
+        "v_fma_f32 v55, v38, v58, v56\n"
+        "v_fma_f32 v55, v55, v58, v57\n"
+        "v_exp_f32 v60, v55\n"
+        "v_cmp_nlt_f32_e64 %[m1], 0, v55\n"
         "v_cmp_lt_i32 vcc, %[pos], %[l0]\n"
         "v_mul_f32 v61, %[d01], v43\n"
         "v_mul_f32 v60, v41, v60\n"
@@ -125,28 +129,26 @@ __device__ __forceinline__ void walk_batch_bwd_2blocks(uint32_t lds, uint32_t re
         "v_fmac_f32 v61, %[d00], v42\n"
         "v_fmac_f32 v61, %[d02], v44\n"
         "v_sub_f32 v61, v61, %[A0]\n"
-        "v_fma_f32 v59, %[T0], v61, -%[tb0]\n"
+        "v_fma_f32 v55, %[T0], v61, -%[tb0]\n"
         "v_mul_f32 %[T0], %[T0], v63\n"
-        "v_mul_f32 v59, v59, v63\n"
+        "v_mul_f32 v55, v55, v63\n"
         "v_fmac_f32 %[A0], v61, v62\n"
         "v_mul_f32 v62, v62, %[T0]\n"
         "s_mov_b64 %[any], vcc\n"
         "v_mul_f32 v46, %[d00], v62\n"
         "v_mul_f32 v47, %[d01], v62\n"
         "v_mul_f32 v48, %[d02], v62\n"
-        "v_mul_f32 v54, v60, v59\n"
-        "v_mul_f32 v49, v58, v54\n"
-        "v_mul_f32 v50, v55, v54\n"
-        "v_mul_f32 v51, v58, v49\n"
-        "v_mul_f32 v52, v55, v49\n"
-        "v_mul_f32 v53, v55, v50\n"
+        "v_mul_f32 v54, v60, v55\n"
+        "v_pk_mul_f32 v[50:51], v[54:55], v[58:59] op_sel_hi:[0,1]\n"
+        "v_pk_mul_f32 v[52:53], v[50:51], v[58:59] op_sel_hi:[0,1]\n"
+        "v_mul_f32 v49, v59, v51\n"
         "s_bitcmp1_b64 %[b1m], %[j]\n"
         "s_cbranch_scc0 4f\n"
         "v_sub_f32 v58, v36, %[fx1]\n"
-        "v_fma_f32 v59, v38, v58, v56\n"
-        "v_fma_f32 v59, v59, v58, v57\n"
-        "v_exp_f32 v60, v59\n"
-        "v_cmp_nlt_f32_e64 %[m1], 0, v59\n"
+        "v_fma_f32 v55, v38, v58, v56\n"
+        "v_fma_f32 v55, v55, v58, v57\n"
+        "v_exp_f32 v60, v55\n"
+        "v_cmp_nlt_f32_e64 %[m1], 0, v55\n"
         "v_cmp_lt_i32 vcc, %[pos], %[l1]\n"
         "v_mul_f32 v61, %[d11], v43\n"
         "v_mul_f32 v60, v41, v60\n"
@@ -160,31 +162,28 @@ __device__ __forceinline__ void walk_batch_bwd_2blocks(uint32_t lds, uint32_t re
         "v_fmac_f32 v61, %[d10], v42\n"
         "v_fmac_f32 v61, %[d12], v44\n"
         "v_sub_f32 v61, v61, %[A1]\n"
-        "v_fma_f32 v59, %[T1], v61, -%[tb1]\n"
+        "v_fma_f32 v55, %[T1], v61, -%[tb1]\n"
         "v_mul_f32 %[T1], %[T1], v63\n"
-        "v_mul_f32 v59, v59, v63\n"
+        "v_mul_f32 v55, v55, v63\n"
         "v_fmac_f32 %[A1], v61, v62\n"
         "v_mul_f32 v62, v62, %[T1]\n"
         "s_or_b64 %[any], %[any], vcc\n"
         "v_fmac_f32 v46, %[d10], v62\n"
         "v_fmac_f32 v47, %[d11], v62\n"
         "v_fmac_f32 v48, %[d12], v62\n"
-        "v_mul_f32 v61, v60, v59\n"
-        "v_fmac_f32 v54, v60, v59\n"
-        "v_mul_f32 v60, v58, v61\n"
-        "v_mul_f32 v59, v55, v61\n"
-        "v_fmac_f32 v49, v58, v61\n"
-        "v_fmac_f32 v50, v55, v61\n"
-        "v_fmac_f32 v51, v58, v60\n"
-        "v_fmac_f32 v52, v55, v60\n"
-        "v_fmac_f32 v53, v55, v59\n"
+        "v_fmac_f32 v54, v60, v55\n"
+        "v_mul_f32 v60, v60, v55\n"
+        "v_pk_mul_f32 v[62:63], v[60:61], v[58:59] op_sel_hi:[0,1]\n"
+        "v_pk_fma_f32 v[50:51], v[60:61], v[58:59], v[50:51] op_sel_hi:[0,1,1]\n"
+        "v_pk_fma_f32 v[52:53], v[62:63], v[58:59], v[52:53] op_sel_hi:[0,1,1]\n"
+        "v_fmac_f32 v49, v59, v63\n"
         "s_branch 4f\n"
         "3:\n"                                        // block 0 takes no part: block 1 does (the entry is in one of the masks)
         "v_sub_f32 v58, v36, %[fx1]\n"
-        "v_fma_f32 v59, v38, v58, v56\n"
-        "v_fma_f32 v59, v59, v58, v57\n"
-        "v_exp_f32 v60, v59\n"
-        "v_cmp_nlt_f32_e64 %[m1], 0, v59\n"
+        "v_fma_f32 v55, v38, v58, v56\n"
+        "v_fma_f32 v55, v55, v58, v57\n"
+        "v_exp_f32 v60, v55\n"
+        "v_cmp_nlt_f32_e64 %[m1], 0, v55\n"
         "v_cmp_lt_i32 vcc, %[pos], %[l1]\n"
         "v_mul_f32 v61, %[d11], v43\n"
         "v_mul_f32 v60, v41, v60\n"
@@ -198,33 +197,32 @@ __device__ __forceinline__ void walk_batch_bwd_2blocks(uint32_t lds, uint32_t re
         "v_fmac_f32 v61, %[d10], v42\n"
         "v_fmac_f32 v61, %[d12], v44\n"
         "v_sub_f32 v61, v61, %[A1]\n"
-        "v_fma_f32 v59, %[T1], v61, -%[tb1]\n"
+        "v_fma_f32 v55, %[T1], v61, -%[tb1]\n"
         "v_mul_f32 %[T1], %[T1], v63\n"
-        "v_mul_f32 v59, v59, v63\n"
+        "v_mul_f32 v55, v55, v63\n"
         "v_fmac_f32 %[A1], v61, v62\n"
         "v_mul_f32 v62, v62, %[T1]\n"
         "s_mov_b64 %[any], vcc\n"
         "v_mul_f32 v46, %[d10], v62\n"
         "v_mul_f32 v47, %[d11], v62\n"
         "v_mul_f32 v48, %[d12], v62\n"
-        "v_mul_f32 v54, v60, v59\n"
-        "v_mul_f32 v49, v58, v54\n"
-        "v_mul_f32 v50, v55, v54\n"
-        "v_mul_f32 v51, v58, v49\n"
-        "v_mul_f32 v52, v55, v49\n"
-        "v_mul_f32 v53, v55, v50\n"
+        "v_mul_f32 v54, v60, v55\n"
+        "v_pk_mul_f32 v[50:51], v[54:55], v[58:59] op_sel_hi:[0,1]\n"
+        "v_pk_mul_f32 v[52:53], v[50:51], v[58:59] op_sel_hi:[0,1]\n"
+        "v_mul_f32 v49, v59, v51\n"
         "4:\n"
         "s_cmp_eq_u64 %[any], 0\n"
         "s_cbranch_scc1 5f\n"                         // no pixel of this wave blends the splat
-        // reduction through LDS: nine rows of the lanes' partial sums, 36 lanes add 16 floats each, two DPP steps, one 9-lane atomic
+        // reduction through LDS: nine rows of the lanes' partial sums, 36 lanes add 16 floats each (packed adds), two DPP steps, one
+        // 9-lane atomic
         "ds_write_b32 %[redw], v46\n"
         "ds_write_b32 %[redw], v47 offset:272\n"
         "ds_write_b32 %[redw], v48 offset:544\n"
-        "ds_write_b32 %[redw], v49 offset:816\n"
-        "ds_write_b32 %[redw], v50 offset:1088\n"
-        "ds_write_b32 %[redw], v51 offset:1360\n"
-        "ds_write_b32 %[redw], v52 offset:1632\n"
-        "ds_write_b32 %[redw], v53 offset:1904\n"
+        "ds_write_b32 %[redw], v50 offset:816\n"
+        "ds_write_b32 %[redw], v51 offset:1088\n"
+        "ds_write_b32 %[redw], v52 offset:1360\n"
+        "ds_write_b32 %[redw], v53 offset:1632\n"
+        "ds_write_b32 %[redw], v49 offset:1904\n"
         "ds_write_b32 %[redw], v54 offset:2176\n"
         "s_mov_b64 exec, %[redm]\n"
         "ds_read_b128 v[36:39], %[redr]\n"
@@ -232,23 +230,16 @@ __device__ __forceinline__ void walk_batch_bwd_2blocks(uint32_t lds, uint32_t re
         "ds_read_b128 v[56:59], %[redr] offset:32\n"
         "ds_read_b128 v[60:63], %[redr] offset:48\n"
         "s_waitcnt lgkmcnt(3)\n"
-        "v_add_f32 v36, v36, v37\n"
-        "v_add_f32 v37, v38, v39\n"
-        "v_add_f32 v36, v36, v37\n"
+        "v_pk_add_f32 v[36:37], v[36:37], v[38:39]\n"
         "s_waitcnt lgkmcnt(2)\n"
-        "v_add_f32 v37, v40, v41\n"
-        "v_add_f32 v38, v42, v43\n"
-        "v_add_f32 v37, v37, v38\n"
-        "v_add_f32 v36, v36, v37\n"
+        "v_pk_add_f32 v[40:41], v[40:41], v[42:43]\n"
         "s_waitcnt lgkmcnt(1)\n"
-        "v_add_f32 v37, v56, v57\n"
-        "v_add_f32 v38, v58, v59\n"
-        "v_add_f32 v37, v37, v38\n"
+        "v_pk_add_f32 v[56:57], v[56:57], v[58:59]\n"
+        "v_pk_add_f32 v[36:37], v[36:37], v[40:41]\n"
         "s_waitcnt lgkmcnt(0)\n"
-        "v_add_f32 v38, v60, v61\n"
-        "v_add_f32 v39, v62, v63\n"
-        "v_add_f32 v38, v38, v39\n"
-        "v_add_f32 v37, v37, v38\n"
+        "v_pk_add_f32 v[60:61], v[60:61], v[62:63]\n"
+        "v_pk_add_f32 v[56:57], v[56:57], v[60:61]\n"
+        "v_pk_add_f32 v[36:37], v[36:37], v[56:57]\n"
         "v_add_f32 v36, v36, v37\n"
         "s_mov_b64 exec, -1\n"
         "s_nop 1\n"                                   // a DPP read of a VGPR two wait states after its write
