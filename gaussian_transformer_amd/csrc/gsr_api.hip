@@ -35,6 +35,7 @@ static std::atomic<int> g_count_lanes{0};      // 1: instrumented compositing ke
 static std::atomic<int> g_deterministic_bwd{0};   // 1: fixed-order reduction of the reverse pass's partial gradients
 static std::atomic<int> g_seg_len{256};           // entries per segment of the reverse pass's work units (multiple of 64); 0: whole half tiles
 static std::atomic<int> g_dense_pergauss{2};      // per-Gaussian backward on the Gaussians with a gradient only, zero rows filled on a second stream: 0 off, 1 on, 2 = from GSR_DENSE_MIN_P Gaussians
+static std::atomic<int> g_dense_fork{2};           // dense per-Gaussian stage: 1 = the second stream is forked after the accumulator rows are cleared, 0 = before, 2 = after below GSR_DENSE_FORK_EARLY_P Gaussians
 static std::atomic<int> g_asm_walk{1};            // 1: compositing walks written in gfx950 assembly where they exist (same results, bit for bit), 0: the C++ walks
 static std::atomic<int> g_fill_in_tail{0};        // 1: with the persistent reverse kernel, the zero rows of Gaussians without a gradient are written by its idle waves
                                                   // (measured at config 3: pergauss_bwd 84 -> 62 us, but the compositing kernel + 40..66 us: off)
@@ -110,6 +111,7 @@ static bool side_stream(DeviceState &ds) {
     return true;
 }
 #define GSR_DENSE_MIN_P 500000
+#define GSR_DENSE_FORK_EARLY_P 2000000
 static const char *const k_stage_names[GSR_NUM_STAGES] = {
     // lists.bin = entries binned per super-tile (count + scan + scatter; round 1's path: depth order + scan); lists.order = per-super-tile order +
     // expansion into the tile lists (sort path: the radix sort); emit_keys / ranges only run on the sort path
@@ -365,6 +367,10 @@ int32_t gsr_set_option(const char *name, int32_t value) {
     }
     if (name && !strcmp(name, "fill_in_tail")) { g_fill_in_tail.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "asm_walk")) { g_asm_walk.store(value ? 1 : 0); return GSR_OK; }
+    if (name && !strcmp(name, "dense_fork")) {
+        if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARGUMENT, "dense_fork must be 0, 1 or 2");
+        g_dense_fork.store(value); return GSR_OK;
+    }
     if (name && !strcmp(name, "dense_pergauss")) {
         if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARGUMENT, "dense_pergauss must be 0, 1 or 2");
         g_dense_pergauss.store(value); return GSR_OK;
@@ -404,6 +410,7 @@ int32_t gsr_get_option(const char *name, int32_t *value) {
     if (name && value && !strcmp(name, "segment_entries")) { *value = g_seg_len.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "fill_in_tail")) { *value = g_fill_in_tail.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "asm_walk")) { *value = g_asm_walk.load(); return GSR_OK; }
+    if (name && value && !strcmp(name, "dense_fork")) { *value = g_dense_fork.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "dense_pergauss")) { *value = g_dense_pergauss.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "poll_timeouts")) { *value = dev_state().poll_timeouts.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "depth_buckets")) { *value = g_depth_buckets.load(); return GSR_OK; }
@@ -749,19 +756,29 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
         DeviceState &ds = dev_state();
         std::lock_guard<std::mutex> lk(ds.mu);
         if (!side_stream(ds)) dense = false;
-        else {
-            HIP_TRY(hipEventRecord(ds.ev_fork, s), "fork event");
-            HIP_TRY(hipStreamWaitEvent(ds.side, ds.ev_fork, 0), "fork wait");
-            HIP_TRY(hipMemsetAsync(pa.vis_count, 0, 256, ds.side), "visible counter");
-            HIP_TRY(launch_gather_visible(pa, ds.side), "gather launch");
-            HIP_TRY(launch_fill_zero(pa, ds.side), "gradient zero-fill launch");
-            HIP_TRY(hipEventRecord(ds.ev_join, ds.side), "join event");
-        }
     }
+    // the fork: after the accumulator rows are cleared, the clearing kernel has the chip to itself (7 us; 18 with the gathering kernel
+    // starting beside it) and the second stream's work starts with the compositing kernel -- config 3: 4 us better; at 5 M Gaussians
+    // the second stream's work (1.2 GB of zeros, 450 k records) outlasts the compositing kernel's shadow and every microsecond of
+    // head start counts: fork first (config 5: 2.37 against 2.42 ms)
+    auto fork = [&]() -> int32_t {
+        DeviceState &ds = dev_state();
+        std::lock_guard<std::mutex> lk(ds.mu);
+        HIP_TRY(hipEventRecord(ds.ev_fork, s), "fork event");
+        HIP_TRY(hipStreamWaitEvent(ds.side, ds.ev_fork, 0), "fork wait");
+        HIP_TRY(hipMemsetAsync(pa.vis_count, 0, 256, ds.side), "visible counter");
+        HIP_TRY(launch_gather_visible(pa, ds.side), "gather launch");
+        HIP_TRY(launch_fill_zero(pa, ds.side), "gradient zero-fill launch");
+        HIP_TRY(hipEventRecord(ds.ev_join, ds.side), "join event");
+        return GSR_OK;
+    };
+    const int fork_late = g_dense_fork.load() == 2 ? (P < GSR_DENSE_FORK_EARLY_P ? 1 : 0) : g_dense_fork.load();
+    if (dense && !fork_late) { const int32_t rc = fork(); if (rc != GSR_OK) return rc; }
     if (det) {
         HIP_TRY(hipMemsetAsync(bwd_ws, 0, align_up(acc_bytes) + det_bytes, s), "zero accumulators");
         if (persistent) HIP_TRY(launch_zero_marked_rows(P, g.touched, g.touch_mark, (float *)bwd_ws, 0, segv, pk_grid, fill_chunk, s), "unit lists");
     } else HIP_TRY(launch_zero_marked_rows(P, g.touched, g.touch_mark, (float *)bwd_ws, acc_rows(P), segv, persistent ? pk_grid : 0, fill_chunk, s), "zero accumulators");
+    if (dense && fork_late) { const int32_t rc = fork(); if (rc != GSR_OK) return rc; }
     tm.mark(9);
     if (R > 0) {
         CompositeBwdArgs ca;
