@@ -65,11 +65,13 @@ const char *gsr_last_error(void);
  *                zero gradients written) and which of them use replica accumulator rows
  *   img_bytes  : per-tile ranges + per-pixel final transmittance / last contributor
  *   bwd_bytes  : scratch used only inside gsr_backward (gradient accumulators: one 64-byte row per Gaussian plus
- *                P/32 + 1024 replica rows; no initialisation needed, gsr_backward clears what it uses) */
+ *                P/32 + 1024 replica rows; behind them the dense per-Gaussian stage's list and record buffer, 4 P + 240 max(131072, P/4)
+ *                bytes; no initialisation needed, gsr_backward clears what it uses) */
 int32_t gsr_workspace_sizes(int32_t P, int32_t W, int32_t H, size_t *geom_bytes, size_t *img_bytes, size_t *bwd_bytes);
 
 /* Size of gsr_backward's scratch workspace for a forward that rendered R pairs: the bwd_bytes of gsr_workspace_sizes,
- * plus, while the option "deterministic_bwd" is on, one 64-byte slot per (pair, wave of the tile). */
+ * plus, while the option "deterministic_bwd" is on, one 64-byte slot per (pair, wave of the tile).  A workspace that only covers the
+ * accumulators is accepted: gsr_backward then keeps the streaming per-Gaussian kernel. */
 int32_t gsr_backward_workspace_bytes(int32_t P, int64_t R, size_t *bytes);
 
 /* Size of the binning workspace of the SORT path for N (Gaussian,tile) pairs (informational).  gsr_forward asks the
@@ -208,6 +210,16 @@ int32_t gsr_debug_read_wave_trace(int32_t which, uint32_t *out /*[4 * max_units]
  *        Gradients equal the unsegmented ones up to the order of float additions.
  *   "fill_in_tail" (default 0): let the persistent reverse kernel's idle waves write the zero gradient rows of Gaussians without a
  *        gradient (measured slower; kept for experiments).
+ *   "asm_walk" (default 1): the innermost loop of both compositing kernels (the walk over a staged batch of splats) in hand-written
+ *        gfx950 assembly; 0 = the C++ walks.  Same images bit for bit; gradients equal up to the order of float additions.  Speed only.
+ *   "dense_pergauss" (0, 1, 2; default 2 = from 500 000 Gaussians): gsr_backward forks a second stream of the library's own (lowest
+ *        priority, one per device, created on first use) on which the zeros of every gradient output are written and the Gaussians
+ *        with a gradient are listed and their inputs copied into a compact buffer while the compositing kernel runs; the per-Gaussian
+ *        kernel then runs on those only.  Applies to shs with M = 16 and scales + rotations (other layouts: the streaming kernel).
+ *        The caller's stream sees one event record and one event wait; the join is enqueued before gsr_backward returns.  Same
+ *        gradients (bit for bit under "deterministic_bwd").  Speed only.
+ *   "dense_fork" (0, 1, 2; default 2): where that fork happens -- 1 after the accumulator rows are cleared, 0 before, 2 = after below
+ *        2 000 000 Gaussians.
  *   Options that change what the forward pass leaves for the reverse pass ("persistent_bwd", "segment_entries", the blocks-per-wave
  *   settings) must not be changed between a gsr_forward and the gsr_backward that belongs to it.
  *   "deterministic_bwd" (default 0): the reverse compositing pass stores the partial gradients of every (wave, pair)
