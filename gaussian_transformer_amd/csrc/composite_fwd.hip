@@ -145,7 +145,7 @@ __device__ __forceinline__ void walk_batch_2blocks(uint32_t lds, uint32_t pos1, 
 template <int NPX, int COUNT, bool ASMW = false>
 __device__ __forceinline__ void fwd_unit(const CompositeArgs &a, float4 *my, const int lane, const int tile, const int sub, const int trace_id,
                                          const int exact_cull) {
-    static_assert(!ASMW || (NPX == 2 && COUNT == 0), "the written-out walk exists for 2 blocks per wave, uninstrumented");
+    static_assert(!ASMW || (NPX == 2 && COUNT != 1), "the written-out walk exists for 2 blocks per wave, without lane counting");
     constexpr int UNITS_PER_TILE = 4 / NPX;
     const int unit = tile * UNITS_PER_TILE + sub;
     const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
@@ -381,8 +381,9 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a, int
 }
 // the default instantiation: written-out walk; 8 waves per SIMD asked for explicitly (the walk's twelve named registers + the loop
 // invariants the compiler hoists came to 65 VGPRs without it)
+template <int COUNT>      // 0, or 2 = with the wave timeline (count_lanes = 2: splat visits are not counted in this walk)
 __global__ __launch_bounds__(256, 8) void composite_fwd_walk_kernel(CompositeArgs a, int nblocks_padded, int exact_cull) {
-    fwd_kernel_body<2, 0, true>(a, nblocks_padded, exact_cull);
+    fwd_kernel_body<2, COUNT, true>(a, nblocks_padded, exact_cull);
 }
 
 template <int NPX>
@@ -391,14 +392,17 @@ static hipError_t launch_fwd(const CompositeArgs &a, int exact_cull, int wpb, hi
     const int units = T * (4 / NPX);
     const int blocks = (units + wpb - 1) / wpb;
     const int padded = (blocks + 7) / 8 * 8;
-    if (a.counters && a.count_mode == 2)
+    if (a.counters && a.count_mode == 2 && NPX == 2 && a.asm_walk)
+        hipLaunchKernelGGL(composite_fwd_walk_kernel<2>, dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4) + (size_t)g_composite_lds_pad, s, a,
+                           padded, exact_cull);
+    else if (a.counters && a.count_mode == 2)
         hipLaunchKernelGGL((composite_fwd_kernel<NPX, 2>), dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4) + (size_t)g_composite_lds_pad, s, a,
                            padded, exact_cull);
     else if (a.counters)
         hipLaunchKernelGGL((composite_fwd_kernel<NPX, 1>), dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4) + (size_t)g_composite_lds_pad, s, a,
                            padded, exact_cull);
     else if (NPX == 2 && a.asm_walk)
-        hipLaunchKernelGGL(composite_fwd_walk_kernel, dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4) + (size_t)g_composite_lds_pad, s, a,
+        hipLaunchKernelGGL(composite_fwd_walk_kernel<0>, dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4) + (size_t)g_composite_lds_pad, s, a,
                            padded, exact_cull);
     else
         hipLaunchKernelGGL((composite_fwd_kernel<NPX, 0>), dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4) + (size_t)g_composite_lds_pad, s, a,

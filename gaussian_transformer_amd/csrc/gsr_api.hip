@@ -724,7 +724,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     const bool persistent = sp.persistent_bwd && R > 0;
     const SegView &segv = im.seg;
     // the written-out reverse walk addresses the accumulator rows with a 32-bit byte offset: rows < 2^26
-    const int bwd_asm = g_asm_walk.load() && !det && !lane_counters(1) && acc_rows(P) < (1u << 26) ? 1 : 0;
+    const int bwd_asm = g_asm_walk.load() && !det && (!lane_counters(1) || g_count_lanes.load() == 2) && acc_rows(P) < (1u << 26) ? 1 : 0;
     const int pk_grid = persistent ? composite_bwd_persistent_grid(gridx * gridy, det ? 1 : 0, lane_counters(1) ? g_count_lanes.load() : 0, bwd_asm) : 0;
     const int fill_chunk = persistent && g_fill_in_tail.load() ? seg_fill_chunk(P) : 0;       // zero-fill units in the persistent kernel's lists
 
