@@ -159,8 +159,12 @@ def main():
         opt = HipAdam([{"params": [p_], "lr": 0.0} for p_ in params], eps=1e-15)     # lr 0: the full Adam arithmetic, parameters (and N) unchanged
     state = {"exchange": True, "consume": True, "ex": ex}
 
+    # the screen-space placeholder the reference's render() passes (gaussian_renderer/__init__.py: zeros, requires_grad, only there to
+    # receive dL/dmeans2D): made once -- the rasterizer never reads it, and a [P, 3] fill kernel per step is the caller's, not the path's
+    means2D_placeholder = torch.zeros((P, 3), dtype=torch.float32, device=dev, requires_grad=True)
+
     def render_backward(b, arena):
-        means2D = torch.zeros((P, 3), dtype=torch.float32, device=dev, requires_grad=True)
+        means2D = means2D_placeholder
         color, radii = GaussianRasterizer(raster_settings=settings[b])(means3D=means3D, means2D=means2D, shs=shs, opacities=opac, scales=scales, rotations=rots)
         mask = composited_mask(color) if (ex_sparse and world > 1) else None
         if arena is None:
