@@ -363,6 +363,199 @@ __device__ __forceinline__ void fwd_unit(const CompositeArgs &a, float4 *my, con
     }
 }
 
+// ---- long lists on small images: one wave per 8x8 BLOCK, two of them (a workgroup) per half tile (round 3) ----
+// On images whose half tiles do not fill the chip twice over, the forward kernel lasts as long as its longest list: every wave is
+// resident from the start and the wave of the longest half tile walks its chain alone (profiles/r03/wave_trace_default.jsonl: 1 458
+// of 4 863 waves alive at half of config 2's kernel, 46 at three quarters).  A lone wave issues one instruction per ~5 cycles whatever
+// its kind, so the chain's speed is the number of instructions per visit: 57 for a two-block visit, 36 for a one-block visit.  Half
+// tiles whose list is longer than `pair_long_n` are therefore walked by a WORKGROUP of two waves, one per block, each with the one-block
+// walk below (same exponent form -- row terms -- as the two-block walk: the reverse pass must take the same decisions).  The two
+// share what the reverse pass expects per half tile: the checkpoint slots (first wave to reach a boundary draws the slot, through an
+// LDS word), and `info` (largest last contributor, checkpoints taken), written by whichever finishes last.
+__device__ __forceinline__ void walk_batch_1block(uint32_t lds, uint32_t pos1, float fx, float fy, unsigned long long &m,
+                                                  unsigned long long &d, WalkState &p) {
+    uint32_t j, pos;
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n"
+        "1:\n"
+        "s_ff1_i32_b64 %[j], %[m]\n"
+        "s_bitset0_b64 %[m], %[j]\n"
+        "v_mad_u32_u24 v61, %[j], 48, %[lds]\n"
+        "ds_read_b128 v[52:55], v61\n"               // px, py, a, b
+        "ds_read_b128 v[56:59], v61 offset:16\n"     // c, opacity, red, green
+        "ds_read_b32 v60, v61 offset:32\n"           // blue
+        "s_add_u32 %[pos], %[j], %[pos1]\n"
+        "s_not_b64 exec, %[d]\n"
+        "s_waitcnt lgkmcnt(2)\n"
+        "v_sub_f32 v61, v53, %[fy]\n"                // dy
+        "v_mul_f32 v62, v61, v55\n"                  // u = b dy
+        "s_waitcnt lgkmcnt(1)\n"
+        "v_mul_f32 v63, v61, v56\n"                  // c dy
+        "v_mul_f32 v63, v61, v63\n"                  // w = (c dy) dy
+        "v_sub_f32 v61, v52, %[fx]\n"                // dx
+        "v_fma_f32 v53, v54, v61, v62\n"             // a dx + u
+        "v_fma_f32 v61, v53, v61, v63\n"             // power (log2 units)
+        "v_exp_f32 v53, v61\n"
+        "v_cmpx_nlt_f32 vcc, 0, v61\n"               // !(power > 0)
+        "v_mul_f32 v53, v57, v53\n"                  // opacity * G
+        "v_cmpx_ngt_f32 vcc, %[amin], v53\n"         // !(alpha < 1/255)
+        "v_min_f32 v55, 0x3f7d70a4, v53\n"           // min(0.99, .)
+        "v_fma_f32 v56, -%[T], v55, %[T]\n"          // T (1 - alpha)
+        "v_cmp_gt_f32 vcc, %[tmin], v56\n"
+        "s_cbranch_vccnz 20f\n"
+        "21:\n"
+        "v_mul_f32 %[T], %[T], v55\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_fmac_f32 %[C2], v60, %[T]\n"
+        "v_fmac_f32 %[C1], v59, %[T]\n"
+        "v_fmac_f32 %[C0], v58, %[T]\n"
+        "v_mov_b32 %[T], v56\n"
+        "v_mov_b32 %[L], %[pos]\n"
+        "s_mov_b64 exec, -1\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_cmp_lg_u64 %[m], 0\n"
+        "s_cbranch_scc1 1b\n"
+        "s_branch 9f\n"
+        "20:\n"
+        "s_or_b64 %[d], %[d], vcc\n"
+        "s_andn2_b64 exec, exec, vcc\n"
+        "s_cmp_eq_u64 %[d], -1\n"
+        "s_cbranch_scc0 21b\n"
+        "s_mov_b64 %[m], 0\n"                        // no pixel left: no further entries
+        "s_branch 21b\n"
+        "9:\n"
+        : [m] "+s"(m), [d] "+s"(d), [j] "=&s"(j), [pos] "=&s"(pos),
+          [T] "+v"(p.T), [C0] "+v"(p.C0), [C1] "+v"(p.C1), [C2] "+v"(p.C2), [L] "+v"(p.last)
+        : [lds] "v"(lds), [pos1] "s"(pos1), [fx] "v"(fx), [fy] "v"(fy), [amin] "s"(GSR_ALPHA_MIN), [tmin] "s"(GSR_T_MIN)
+        : "memory", "scc", "vcc", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+}
+
+struct PairShared {                 // one per workgroup (LDS), zeroed before the waves part ways
+    uint32_t slot[GSR_SEG_MAXCK + 1];   // checkpoint k: 0 = nobody was here yet, 1 = being drawn, 2 + s = pool slot s, ~0u = the pool's share is used up
+    uint32_t ml[2], nck[2];             // what each wave found: largest last contributor, checkpoints it wrote
+    uint32_t finished;                  // waves done (the second one files the half tile)
+};
+
+// block wave `w` (0 = left, 1 = right block) of half tile `sub` of `tile`
+template <int COUNT>
+__device__ __forceinline__ void fwd_unit_pair(const CompositeArgs &a, float4 *my, PairShared *ps, const int lane, const int tile, const int sub,
+                                              const int w, const int trace_id, const int exact_cull) {
+    const int unit = tile * 2 + sub;
+    const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
+    const int tx = tile % a.gridx, ty = tile / a.gridx;
+    const uint2 range = a.ranges[tile];
+    const int n = __builtin_amdgcn_readfirstlane((int)(range.y - range.x));
+    const float4 *rec4 = reinterpret_cast<const float4 *>(a.rec);
+    const int blk = sub * 2 + w;
+    const int x0 = tx * GSR_TILE + (blk & 1) * 8, y0 = ty * GSR_TILE + (blk >> 1) * 8;
+    const int x = x0 + (lane & 7), y = y0 + (lane >> 3);
+    const bool inside = x < a.W && y < a.H;
+    const float fx = (float)x, fy = (float)y;
+    const float bxa = (float)x0, bya = (float)y0, bxb = (float)min(x0 + 7, a.W - 1), byb = (float)min(y0 + 7, a.H - 1);
+    WalkState p = {1.f, 0.f, 0.f, 0.f, 0u};
+    unsigned long long done = __builtin_amdgcn_ballot_w64(!inside);
+    const bool seg_on = a.seg_len > 0;
+    if (seg_on && unit == 0 && w == 0 && lane == 0) a.seg.hdr[SEG_SEG] = (uint32_t)a.seg_len;
+    int next_ck = seg_on ? a.seg_len : 0x7fffffff, n_ck = 0;
+    uint32_t ck_slots = 0u;                           // lane j: pool slot of checkpoint j
+    unsigned long long c_staged = 0;
+    for (int base = 0; base < n && done != ~0ull; base += 64) {
+        const int cnt = min(64, n - base);
+        if (base == next_ck) {                        // wave-uniform; both waves of the pair pass the same boundaries while they live
+            next_ck = 0x7fffffff;
+            const int k = base / a.seg_len - 1;       // checkpoint index of this boundary
+            if (k < GSR_SEG_MAXCK) {
+                uint32_t got = 0u;
+                if (lane == 0) {
+                    uint32_t old = atomicCAS(&ps->slot[k], 0u, 1u);
+                    if (old == 0u) {                  // first of the pair here: draw the slot for both
+                        const uint32_t band = (uint32_t)unit / a.seg.band_units, share = a.seg.pool_cap / GSR_SEG_BANDS;
+                        uint32_t sl = atomicAdd(&a.seg.hdr[SEG_POOL + GSR_SEG_CTR_STRIDE * band], 1u);
+                        old = sl < share ? 2u + band * share + sl : ~0u;
+                        __hip_atomic_store(&ps->slot[k], old, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        while (old == 1u) { __builtin_amdgcn_s_sleep(2); old = __hip_atomic_load(&ps->slot[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                    }
+                    got = old;
+                }
+                got = __builtin_amdgcn_readfirstlane(got);
+                if (got != ~0u) {
+                    uint32_t slot = got - 2u;
+                    if (!GSR_IDX_OK(slot, a.seg.pool_cap, a.seg.hdr + GSR_DBG_SEG_WORD, GSR_BOUND_POOL_SLOT)) slot = 0u;
+                    a.seg.pool[(size_t)slot * 128 + w * 64 + lane] = make_float4(p.T, p.C0, p.C1, p.C2);
+                    p.C0 = 0.f; p.C1 = 0.f; p.C2 = 0.f;
+                    if (lane == k) ck_slots = slot;
+                    n_ck = k + 1;
+                    next_ck = base + a.seg_len;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        bool reach = false;
+        if (lane < cnt && GSR_IDX_OK((size_t)range.x + base + lane, a.contrib_stride, a.seg.hdr + GSR_DBG_SEG_WORD, GSR_BOUND_FWD_LIST_READ)) {
+            const uint32_t g = a.point_list[range.x + base + lane];
+            const float4 r0 = rec4[3 * (size_t)g], r1 = rec4[3 * (size_t)g + 1], r2 = rec4[3 * (size_t)g + 2];
+            reach = true;
+            if (exact_cull && r2.z > 0.f) {
+                const float invA = 1.f / r0.z, invC = 1.f / r1.x;
+                reach = block_reachable(r0.x, r0.y, r0.z, r0.w, r1.x, invA, invC, r2.z, bxa, bxb, bya, byb);
+            }
+            if (reach) a.touched[g] = (uint8_t)a.touch_mark;
+            a.contrib[(size_t)blk * a.contrib_stride + range.x + base + lane] = (uint8_t)(reach ? 1u : 0u);
+            const StagedConic sc = stage_conic(r0.z, r0.w, r1.x);
+            my[lane * 3 + 0] = make_float4(r0.x, r0.y, sc.a, sc.b);
+            my[lane * 3 + 1] = make_float4(sc.c, r1.y, r1.z, r1.w);
+            my[lane * 3 + 2] = make_float4(r2.x, 0.f, 0.f, 0.f);
+        }
+        unsigned long long m = __builtin_amdgcn_ballot_w64(reach);
+        if (COUNT) c_staged += cnt;
+        __builtin_amdgcn_wave_barrier();
+        if (m != 0ull) {
+            walk_batch_1block((uint32_t)(uintptr_t)my, (uint32_t)(base + 1), fx, fy, m, done, p);
+            // (wave-uniform, said so for the compiler: carried around this loop as an asm output it would be given vector registers)
+            done = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(done >> 32)) << 32) |
+                   (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)done);
+        }
+    }
+    if (COUNT && lane == 0 && a.counters && a.counters->trace && (unsigned long long)trace_id < a.counters->trace_cap)
+        a.counters->trace[trace_id] = make_uint4((uint32_t)t_start, (uint32_t)wall_clock64(), (uint32_t)c_staged,
+                                                 (__builtin_amdgcn_s_getreg(30724) & 0xffffu) << 12 | (__builtin_amdgcn_s_getreg(6164) & 0xfu) << 28);
+    if (seg_on) {
+        n_ck = __builtin_amdgcn_readfirstlane(n_ck);      // (wave-uniform; said so for the compiler: readlane's index below)
+        // back over the checkpoints this wave wrote: its own segment's colour -> the colour composited behind the boundary
+        for (int j = n_ck - 1; j >= 0; j--) {
+            const uint32_t slot = __builtin_amdgcn_readlane(ck_slots, j);
+            float4 *ck = a.seg.pool + (size_t)slot * 128 + w * 64 + lane;
+            const float4 c = *ck;
+            *ck = make_float4(c.x, p.C0, p.C1, p.C2);
+            p.C0 += c.y; p.C1 += c.z; p.C2 += c.w;
+        }
+        int ml = (int)p.last;
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) ml = max(ml, __shfl_xor(ml, sft));
+        if (lane == 0) {
+            ps->ml[w] = (uint32_t)ml; ps->nck[w] = (uint32_t)n_ck;
+            __threadfence_block();
+            if (atomicAdd(&ps->finished, 1u) == 1u) {             // the other wave is done too: file the half tile
+                __threadfence_block();
+                const uint32_t nk = max(ps->nck[0], ps->nck[1]);
+                a.seg.info[unit] = make_uint2(max(ps->ml[0], ps->ml[1]), nk);
+                for (uint32_t k = 0; k < 8u; k++)
+                    a.seg.ck_slot[(size_t)unit * 8 + k] = (k < nk && ps->slot[k] >= 2u && ps->slot[k] != ~0u) ? ps->slot[k] - 2u : 0u;
+            }
+        }
+    }
+    if (inside) {
+        const size_t HW = (size_t)a.W * a.H;
+        const size_t pix = (size_t)y * a.W + (size_t)x;
+        a.final_T[pix] = p.T;
+        a.n_contrib[pix] = p.last;
+        a.out_color[pix] = p.C0 + p.T * a.bg[0];
+        a.out_color[HW + pix] = p.C1 + p.T * a.bg[1];
+        a.out_color[2 * HW + pix] = p.C2 + p.T * a.bg[2];
+    }
+}
+
 // classic decomposition: one wave per NPX blocks of a tile, XCD-banded
 template <int NPX, int COUNT, bool ASMW>
 __device__ __forceinline__ void fwd_kernel_body(const CompositeArgs &a, int nblocks_padded, int exact_cull) {
@@ -386,12 +579,38 @@ __global__ __launch_bounds__(256, 8) void composite_fwd_walk_kernel(CompositeArg
     fwd_kernel_body<2, COUNT, true>(a, nblocks_padded, exact_cull);
 }
 
+// small images: a workgroup of two waves per half tile; a long list is walked by both (one block each), a short one by the first
+// (both blocks, the walk above) while the second leaves at once
+template <int COUNT>
+__global__ __launch_bounds__(128, 8) void composite_fwd_pair_kernel(CompositeArgs a, int nblocks_padded, int exact_cull) {
+    extern __shared__ __align__(16) float4 stage_dyn[];     // [2 waves][64 * 3]
+    __shared__ PairShared ps;
+    const int T = a.gridx * a.gridy;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int unit = xcd_band_unit_f(blockIdx.x, nblocks_padded);
+    const int tile = unit >> 1, sub = unit & 1;
+    if (tile >= T) return;                            // workgroup-uniform
+    if (threadIdx.x < sizeof(PairShared) / 4) reinterpret_cast<uint32_t *>(&ps)[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint2 range = a.ranges[tile];
+    const int n_list = __builtin_amdgcn_readfirstlane((int)(range.y - range.x));      // (told to the compiler: wave-uniform)
+    if (n_list > a.pair_long_n) fwd_unit_pair<COUNT>(a, stage_dyn + w * (64 * 3), &ps, lane, tile, sub, w, unit * 2 + w, exact_cull);
+    else if (w == 0) fwd_unit<2, COUNT, true>(a, stage_dyn, lane, tile, sub, unit * 2, exact_cull);
+}
+
 template <int NPX>
 static hipError_t launch_fwd(const CompositeArgs &a, int exact_cull, int wpb, hipStream_t s) {
     const int T = a.gridx * a.gridy;
     const int units = T * (4 / NPX);
     const int blocks = (units + wpb - 1) / wpb;
     const int padded = (blocks + 7) / 8 * 8;
+    if (NPX == 2 && a.asm_walk && a.pair_long_n > 0 && !(a.counters && a.count_mode == 1)) {
+        const int pblocks = (units + 7) / 8 * 8;      // one workgroup per half tile
+        const size_t plds = (size_t)2 * 64 * 3 * sizeof(float4) + (size_t)g_composite_lds_pad;
+        if (a.counters && a.count_mode == 2) hipLaunchKernelGGL(composite_fwd_pair_kernel<2>, dim3(pblocks), dim3(128), plds, s, a, pblocks, exact_cull);
+        else hipLaunchKernelGGL(composite_fwd_pair_kernel<0>, dim3(pblocks), dim3(128), plds, s, a, pblocks, exact_cull);
+        return hipGetLastError();
+    }
     if (a.counters && a.count_mode == 2 && NPX == 2 && a.asm_walk)
         hipLaunchKernelGGL(composite_fwd_walk_kernel<2>, dim3(padded), dim3(64 * wpb), (size_t)wpb * 64 * 3 * sizeof(float4) + (size_t)g_composite_lds_pad, s, a,
                            padded, exact_cull);

@@ -36,6 +36,7 @@ static std::atomic<int> g_deterministic_bwd{0};   // 1: fixed-order reduction of
 static std::atomic<int> g_seg_len{256};           // entries per segment of the reverse pass's work units (multiple of 64); 0: whole half tiles
 static std::atomic<int> g_dense_pergauss{2};      // per-Gaussian backward on the Gaussians with a gradient only, zero rows filled on a second stream: 0 off, 1 on, 2 = from GSR_DENSE_MIN_P Gaussians
 static std::atomic<int> g_dense_fork{2};           // dense per-Gaussian stage: 1 = the second stream is forked after the accumulator rows are cleared, 0 = before, 2 = after below GSR_DENSE_FORK_EARLY_P Gaussians
+static std::atomic<int> g_fwd_pair_long{-1};       // forward pass on small images (seg_plan: persistent reverse kernel in use): half tiles whose list exceeds this many entries are walked by two waves, one per block; 0 = off, -1 = GSR_PAIR_LONG_DEFAULT
 static std::atomic<int> g_asm_walk{1};            // 1: compositing walks written in gfx950 assembly where they exist (same results, bit for bit), 0: the C++ walks
 static std::atomic<int> g_fill_in_tail{0};        // 1: with the persistent reverse kernel, the zero rows of Gaussians without a gradient are written by its idle waves
                                                   // (measured at config 3: pergauss_bwd 84 -> 62 us, but the compositing kernel + 40..66 us: off)
@@ -110,6 +111,7 @@ static bool side_stream(DeviceState &ds) {
     }
     return true;
 }
+#define GSR_PAIR_LONG_DEFAULT 64
 #define GSR_DENSE_MIN_P 500000
 #define GSR_DENSE_FORK_EARLY_P 2000000
 static const char *const k_stage_names[GSR_NUM_STAGES] = {
@@ -367,6 +369,7 @@ int32_t gsr_set_option(const char *name, int32_t value) {
     }
     if (name && !strcmp(name, "fill_in_tail")) { g_fill_in_tail.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "asm_walk")) { g_asm_walk.store(value ? 1 : 0); return GSR_OK; }
+    if (name && !strcmp(name, "fwd_pair_long")) { g_fwd_pair_long.store(value < -1 ? -1 : value); return GSR_OK; }
     if (name && !strcmp(name, "dense_fork")) {
         if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARGUMENT, "dense_fork must be 0, 1 or 2");
         g_dense_fork.store(value); return GSR_OK;
@@ -410,6 +413,7 @@ int32_t gsr_get_option(const char *name, int32_t *value) {
     if (name && value && !strcmp(name, "segment_entries")) { *value = g_seg_len.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "fill_in_tail")) { *value = g_fill_in_tail.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "asm_walk")) { *value = g_asm_walk.load(); return GSR_OK; }
+    if (name && value && !strcmp(name, "fwd_pair_long")) { *value = g_fwd_pair_long.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "dense_fork")) { *value = g_dense_fork.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "dense_pergauss")) { *value = g_dense_pergauss.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "poll_timeouts")) { *value = dev_state().poll_timeouts.load(); return GSR_OK; }
@@ -666,6 +670,10 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     const SegPlan sp = seg_plan(W, H);
     ca.seg_len = sp.seg_len;
     ca.asm_walk = g_asm_walk.load();
+    {   // long lists by pairs of block waves: only where the longest list sets the kernel's time (the images the persistent reverse kernel serves)
+        const int pl = g_fwd_pair_long.load();
+        ca.pair_long_n = sp.small_image && g_fwd_npx.load() == 2 ? (pl < 0 ? GSR_PAIR_LONG_DEFAULT : pl) : 0;
+    }
     HIP_TRY(launch_composite_fwd(ca, g_fwd_npx.load(), pa.exact_cull, g_wpb.load(), s), "composite launch");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "composite");
     tm.mark(-1);

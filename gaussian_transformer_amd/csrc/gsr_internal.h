@@ -303,6 +303,7 @@ struct CompositeArgs {
     SegView seg;                 // checkpoints + reverse work units (used by the 2-blocks-per-wave kernel when seg_len > 0)
     int seg_len;                 // entries per segment (multiple of 64); 0: no checkpoints, no units
     int asm_walk;                // 1: the written-out splat walk (composite_fwd.hip::walk_batch_2blocks) where it exists, 0: the C++ walk
+    int pair_long_n;             // > 0: composite_fwd_pair_kernel -- half tiles with more list entries than this are walked by two waves, one per block
 };
 hipError_t launch_composite_fwd(const CompositeArgs &a, int npx, int exact_cull, int waves_per_block, hipStream_t s);
 

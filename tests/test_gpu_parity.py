@@ -750,3 +750,37 @@ def test_dense_per_gaussian_stage_matches_the_streaming_one(kw):
         assert np.array_equal(v, b[k]), (k, float(np.abs(v - b[k]).max()))
         some = some or np.abs(v).max() > 0
     assert some
+
+
+@pytest.mark.parametrize("kw", [
+    dict(P=20000, width=250, height=131, sh_degree=1, s0=0.05, seed=7),          # ragged edge tiles, long lists, saturating pixels
+    dict(P=60000, width=320, height=200, sh_degree=0, s0=0.04, seed=11),         # several checkpoints per half tile
+    dict(P=300000, width=800, height=800, sh_degree=0, s0=0.01, seed=32),
+])
+@pytest.mark.parametrize("long_n", [64, 256])
+def test_forward_by_pairs_of_block_waves_agrees(kw, long_n):
+    """On small images half tiles with long lists are walked by a workgroup of two waves, one per 8x8 block, which share the
+    half tile's checkpoint slots and file its `info` together (composite_fwd.hip::fwd_unit_pair).  Colour, final transmittance,
+    last contributor and lists must equal the one-wave-per-half-tile kernel's bit for bit; the gradients -- through the persistent,
+    segmented reverse kernel that starts from those checkpoints -- within the order-of-addition tolerance."""
+    from gaussian_transformer_amd import _lib
+    sc = synth.make_scene(**kw)
+    S = oracle_scene(sc)
+    _lib.set_option("fwd_pair_long", 0)
+    try:
+        a = _stage_dump(S)
+        ga = hip_forward_backward(S, sc.dL_dimage)
+        _lib.set_option("fwd_pair_long", long_n)
+        b = _stage_dump(S)
+        gb = hip_forward_backward(S, sc.dL_dimage)
+    finally:
+        _lib.set_option("fwd_pair_long", -1)
+    assert a["n"] == b["n"] and a["n"] > 0
+    T = ((S.W + 15) // 16) * ((S.H + 15) // 16)
+    assert (a["ranges"][:, 1] - a["ranges"][:, 0]).max() > long_n          # the pair path ran
+    for k in ("color", "final_T", "n_contrib", "point_list", "ranges"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(ga["color"], gb["color"])
+    for k, v in ga["grads"].items():
+        if v is not None:
+            assert grad_err(v, gb["grads"][k]) <= 2e-4, k
