@@ -212,6 +212,10 @@ int32_t gsr_debug_read_wave_trace(int32_t which, uint32_t *out /*[4 * max_units]
  *        gradient (measured slower; kept for experiments).
  *   "asm_walk" (default 1): the innermost loop of both compositing kernels (the walk over a staged batch of splats) in hand-written
  *        gfx950 assembly; 0 = the C++ walks.  Same images bit for bit; gradients equal up to the order of float additions.  Speed only.
+ *   "fwd_pair_long" (default -1 = 64; 0 = off): on images of at most 6144 tiles (where "persistent_bwd" = 2 applies) the forward
+ *        compositing kernel walks a half tile whose list has more entries than this with a workgroup of two waves, one per 8x8 block,
+ *        instead of one wave over both blocks: the kernel's time there is its longest list walked alone, and a one-block visit is
+ *        fewer instructions.  Same images bit for bit.  Needs fwd_blocks_per_wave = 2 and "asm_walk".  Speed only.
  *   "dense_pergauss" (0, 1, 2; default 2 = from 500 000 Gaussians): gsr_backward forks a second stream of the library's own (lowest
  *        priority, one per device, created on first use) on which the zeros of every gradient output are written and the Gaussians
  *        with a gradient are listed and their inputs copied into a compact buffer while the compositing kernel runs; the per-Gaussian
