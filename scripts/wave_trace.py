@@ -36,6 +36,9 @@ def main():
         sc = synth.make_config(cfg, seed=0)
         count_once(sc, dev, opts)           # warm-up (allocations, first-use set-up); also the lane-slot counters
         cnt = count_once(sc, dev, opts)
+        for which in (0, 1):                # reading clears the timeline: the counting runs above filed their waves too (other ids)
+            junk = np.zeros((1 << 20, 4), dtype=np.uint32)
+            _lib.check(lib.gsr_debug_read_wave_trace(which, junk.ctypes.data_as(C.c_void_p), 1 << 20), "clear trace")
         lib.gsr_set_profiling(1)
         count_once(sc, dev, opts, mode=2)   # wave timeline only: the kernels run at their normal speed
         lib.gsr_set_profiling(0)
