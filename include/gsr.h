@@ -212,6 +212,8 @@ int32_t gsr_debug_read_wave_trace(int32_t which, uint32_t *out /*[4 * max_units]
  *        gradient (measured slower; kept for experiments).
  *   "asm_walk" (default 1): the innermost loop of both compositing kernels (the walk over a staged batch of splats) in hand-written
  *        gfx950 assembly; 0 = the C++ walks.  Same images bit for bit; gradients equal up to the order of float additions.  Speed only.
+ *   "composite_lds_pad" (bytes, default 0): extra dynamic LDS per compositing workgroup (occupancy experiments only).
+ *   "poll_timeouts" (read-only through gsr_get_option): read-backs of the pair count whose pinned-word poll timed out on this device.
  *   "fwd_pair_long" (default -1 = 64; 0 = off): on images of at most 6144 tiles (where "persistent_bwd" = 2 applies) the forward
  *        compositing kernel walks a half tile whose list has more entries than this with a workgroup of two waves, one per 8x8 block,
  *        instead of one wave over both blocks: the kernel's time there is its longest list walked alone, and a one-block visit is

@@ -131,3 +131,15 @@ def test_gradient_arena_views(oracle_backend):
         assert f is flat and rasterizer._grad_arena is flat
     assert rasterizer._grad_arena is None
     assert all(torch.isfinite(g).all() for g in ref_g)
+
+
+def test_every_option_the_library_accepts_is_documented_in_the_header():
+    """include/gsr.h is the contract: a knob gsr_set_option / gsr_get_option knows must be described there."""
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    api = open(os.path.join(root, "gaussian_transformer_amd", "csrc", "gsr_api.hip")).read()
+    hdr = open(os.path.join(root, "include", "gsr.h")).read()
+    names = sorted(set(re.findall(r'strcmp\(name, "([a-z_0-9]+)"\)', api)))
+    assert len(names) > 15
+    missing = [n for n in names if f'"{n}"' not in hdr]
+    assert not missing, missing
