@@ -784,3 +784,26 @@ def test_forward_by_pairs_of_block_waves_agrees(kw, long_n):
     for k, v in ga["grads"].items():
         if v is not None:
             assert grad_err(v, gb["grads"][k]) <= 2e-4, k
+
+
+@pytest.mark.parametrize("kw", [
+    dict(P=20000, width=250, height=131, sh_degree=1, s0=0.05, seed=7),
+    dict(P=200000, width=1920, height=1080, sh_degree=3, s0=0.01, seed=3),       # > 6144 tiles: one workgroup per tile pair, not the persistent kernel
+])
+def test_compositing_with_several_waves_per_workgroup(kw):
+    """`composite_waves_per_block` > 1 puts several waves' LDS slices into one workgroup: the assembly walks address theirs through a
+    VGPR (forward) and through M0 + offset (the reverse pass's reduction rows) -- same image, same gradients as one wave per workgroup."""
+    from gaussian_transformer_amd import _lib
+    sc = synth.make_scene(**kw)
+    S = oracle_scene(sc)
+    a = hip_forward_backward(S, sc.dL_dimage)
+    for wpb in (2, 4):
+        _lib.set_option("composite_waves_per_block", wpb)
+        try:
+            b = hip_forward_backward(S, sc.dL_dimage)
+        finally:
+            _lib.set_option("composite_waves_per_block", 1)
+        assert np.array_equal(a["color"], b["color"]), wpb
+        for k, v in a["grads"].items():
+            if v is not None:
+                assert grad_err(v, b["grads"][k]) <= 2e-4, (wpb, k)
