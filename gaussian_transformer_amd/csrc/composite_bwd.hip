@@ -640,6 +640,27 @@ __global__ __launch_bounds__(64, 8) void composite_bwd_pk_walk_kernel(CompositeB
     bwd_pk_body<COUNT, false, true>(a);
 }
 
+// Large images (round 3): one wave per half tile as in the classic kernel, but in the order of plan_units' lists -- per band the longest
+// half tiles first (lengths filed by the forward pass, CompositeArgs::lpt_span) -- so that what the second generation of waves has left
+// to do at the end of the kernel is short work.  Static assignment (workgroup b takes entry b / 32 of band b % 32): no tickets.
+__global__ __launch_bounds__(64, 8) void composite_bwd_lpt_kernel(CompositeBwdArgs a) {
+    extern __shared__ __align__(16) float4 stage_dyn[];
+    const int lane = threadIdx.x;
+    const uint32_t band = blockIdx.x & (GSR_SEG_BANDS - 1), idx = blockIdx.x / GSR_SEG_BANDS;
+    if (idx >= a.seg.hdr[SEG_BCOUNT + band]) return;             // workgroup-uniform
+    uint4 u = a.seg.bq[seg_list_base(a.seg, (int)band) + idx];
+    u.x = __builtin_amdgcn_readfirstlane(u.x); u.y = __builtin_amdgcn_readfirstlane(u.y);
+    u.z = __builtin_amdgcn_readfirstlane(u.z); u.w = __builtin_amdgcn_readfirstlane(u.w);
+    BwdTally tl;
+    bwd_unit<2, 0, false, true>(a, stage_dyn, lane, (int)(u.x >> 1), (int)(u.x & 1u), (int)u.y, (int)u.z, u.w, tl);
+}
+hipError_t launch_composite_bwd_lpt(const CompositeBwdArgs &a, hipStream_t s) {
+    if (a.gridx * a.gridy <= 0) return hipSuccess;
+    const unsigned grid = GSR_SEG_BANDS * a.seg.band_units;
+    hipLaunchKernelGGL(composite_bwd_lpt_kernel, dim3(grid), dim3(64), (size_t)BWD_LDS_F4 * sizeof(float4) + (size_t)g_composite_lds_pad, s, a);
+    return hipGetLastError();
+}
+
 // The unit list of one band (one workgroup of 256 threads): every half tile's pieces -- [k seg, (k+1) seg) below each checkpoint the
 // forward wave took, and the top piece up to the last contributor -- counting-sorted by length, longest first.  Runs next to the
 // clearing of the accumulator rows and has to be done when that is (~9 us): everything it reads is requested up front (eight half

@@ -183,7 +183,8 @@ __device__ __forceinline__ void fwd_unit(const CompositeArgs &a, float4 *my, con
     // stores per pixel the transmittance so far and the colour accumulated SINCE THE PREVIOUS CHECKPOINT, then restarts the colour
     // sums: the colour behind a boundary is later formed as a sum of per-segment colours, never as a difference of large sums.
     const bool seg_on = NPX == 2 && a.seg_len > 0;
-    if (seg_on && unit == 0 && lane == 0) a.seg.hdr[SEG_SEG] = (uint32_t)a.seg_len;     // tells the reverse pass that units were filed
+    const bool file_info = NPX == 2 && (seg_on || a.lpt_span > 0);                      // lengths for the reverse pass's planner
+    if (file_info && unit == 0 && lane == 0) a.seg.hdr[SEG_SEG] = (uint32_t)(seg_on ? a.seg_len : a.lpt_span);     // tells the reverse pass that units were filed
     int next_ck = seg_on ? a.seg_len : 0x7fffffff, n_ck = 0;
     uint32_t ck_slots = 0u;                           // lane j holds the pool slot of checkpoint j (boundary (j + 1) seg_len)
     unsigned long long c_staged = 0, c_visits = 0, c_blocks = 0, c_ok = 0, c_past = 0, c_alpha = 0, c_dead = 0;
@@ -325,7 +326,7 @@ __device__ __forceinline__ void fwd_unit(const CompositeArgs &a, float4 *my, con
                                                  (uint32_t)min(c_visits, 4095ull) | (__builtin_amdgcn_s_getreg(30724) & 0xffffu) << 12 |   // HW_ID[15:0]: wave, simd, pipe, cu, sh, se
                                                  (__builtin_amdgcn_s_getreg(6164) & 0xfu) << 28);                                           // XCC_ID
     }
-    if (NPX == 2 && seg_on) {
+    if (file_info) {
         // back over the checkpoints: each one's colour (its own segment's) is replaced by the colour composited BEHIND its
         // boundary, what the reverse pass starts from; the running sum ends as the pixel's whole colour
         for (int j = n_ck - 1; j >= 0; j--) {

@@ -37,6 +37,7 @@ static std::atomic<int> g_seg_len{256};           // entries per segment of the 
 static std::atomic<int> g_dense_pergauss{2};      // per-Gaussian backward on the Gaussians with a gradient only, zero rows filled on a second stream: 0 off, 1 on, 2 = from GSR_DENSE_MIN_P Gaussians
 static std::atomic<int> g_dense_fork{2};           // dense per-Gaussian stage: 1 = the second stream is forked after the accumulator rows are cleared, 0 = before, 2 = after below GSR_DENSE_FORK_EARLY_P Gaussians
 static std::atomic<int> g_fwd_pair_long{-1};       // forward pass on small images (seg_plan: persistent reverse kernel in use): half tiles whose list exceeds this many entries are walked by two waves, one per block; 0 = off, -1 = GSR_PAIR_LONG_DEFAULT
+static std::atomic<int> g_bwd_lpt{1};             // large images: the reverse pass's half tiles in order of decreasing length (composite_bwd_lpt_kernel); 0 = in tile order
 static std::atomic<int> g_asm_walk{1};            // 1: compositing walks written in gfx950 assembly where they exist (same results, bit for bit), 0: the C++ walks
 static std::atomic<int> g_fill_in_tail{0};        // 1: with the persistent reverse kernel, the zero rows of Gaussians without a gradient are written by its idle waves
                                                   // (measured at config 3: pergauss_bwd 84 -> 62 us, but the compositing kernel + 40..66 us: off)
@@ -112,6 +113,7 @@ static bool side_stream(DeviceState &ds) {
     return true;
 }
 #define GSR_PAIR_LONG_DEFAULT 64
+#define GSR_LPT_SPAN 512              // length classes of the reverse pass's order on large images: 16 of 32 entries (SegView, plan_units)
 #define GSR_DENSE_MIN_P 500000
 #define GSR_DENSE_FORK_EARLY_P 2000000
 static const char *const k_stage_names[GSR_NUM_STAGES] = {
@@ -369,6 +371,7 @@ int32_t gsr_set_option(const char *name, int32_t value) {
     }
     if (name && !strcmp(name, "fill_in_tail")) { g_fill_in_tail.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "asm_walk")) { g_asm_walk.store(value ? 1 : 0); return GSR_OK; }
+    if (name && !strcmp(name, "bwd_lpt")) { g_bwd_lpt.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "fwd_pair_long")) { g_fwd_pair_long.store(value < -1 ? -1 : value); return GSR_OK; }
     if (name && !strcmp(name, "dense_fork")) {
         if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARGUMENT, "dense_fork must be 0, 1 or 2");
@@ -413,6 +416,7 @@ int32_t gsr_get_option(const char *name, int32_t *value) {
     if (name && value && !strcmp(name, "segment_entries")) { *value = g_seg_len.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "fill_in_tail")) { *value = g_fill_in_tail.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "asm_walk")) { *value = g_asm_walk.load(); return GSR_OK; }
+    if (name && value && !strcmp(name, "bwd_lpt")) { *value = g_bwd_lpt.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "fwd_pair_long")) { *value = g_fwd_pair_long.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "dense_fork")) { *value = g_dense_fork.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "dense_pergauss")) { *value = g_dense_pergauss.load(); return GSR_OK; }
@@ -674,6 +678,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
         const int pl = g_fwd_pair_long.load();
         ca.pair_long_n = sp.small_image && g_fwd_npx.load() == 2 ? (pl < 0 ? GSR_PAIR_LONG_DEFAULT : pl) : 0;
     }
+    ca.lpt_span = (!sp.small_image && sp.seg_len == 0 && g_bwd_lpt.load() && g_fwd_npx.load() == 2 && g_bwd_npx.load() == 2 && T <= (1 << 28)) ? GSR_LPT_SPAN : 0;
     HIP_TRY(launch_composite_fwd(ca, g_fwd_npx.load(), pa.exact_cull, g_wpb.load(), s), "composite launch");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "composite");
     tm.mark(-1);
@@ -734,6 +739,8 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     // the written-out reverse walk addresses the accumulator rows with a 32-bit byte offset: rows < 2^26
     const int bwd_asm = g_asm_walk.load() && !det && (!lane_counters(1) || g_count_lanes.load() == 2) && acc_rows(P) < (1u << 26) ? 1 : 0;
     const int pk_grid = persistent ? composite_bwd_persistent_grid(gridx * gridy, det ? 1 : 0, lane_counters(1) ? g_count_lanes.load() : 0, bwd_asm) : 0;
+    // large images: half tiles in order of decreasing length (the forward pass filed the lengths when it ran with the same options)
+    const bool lpt = !persistent && bwd_asm && !lane_counters(1) && g_bwd_lpt.load() && !sp.small_image && bwd_npx == 2 && g_fwd_npx.load() == 2 && R > 0 && g_wpb.load() == 1;
     const int fill_chunk = persistent && g_fill_in_tail.load() ? seg_fill_chunk(P) : 0;       // zero-fill units in the persistent kernel's lists
 
     PergaussBwdArgs pa;
@@ -785,7 +792,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
     if (det) {
         HIP_TRY(hipMemsetAsync(bwd_ws, 0, align_up(acc_bytes) + det_bytes, s), "zero accumulators");
         if (persistent) HIP_TRY(launch_zero_marked_rows(P, g.touched, g.touch_mark, (float *)bwd_ws, 0, segv, pk_grid, fill_chunk, s), "unit lists");
-    } else HIP_TRY(launch_zero_marked_rows(P, g.touched, g.touch_mark, (float *)bwd_ws, acc_rows(P), segv, persistent ? pk_grid : 0, fill_chunk, s), "zero accumulators");
+    } else HIP_TRY(launch_zero_marked_rows(P, g.touched, g.touch_mark, (float *)bwd_ws, acc_rows(P), segv, persistent ? pk_grid : (lpt ? 1 : 0), fill_chunk, s), "zero accumulators");
     if (dense && fork_late) { const int32_t rc = fork(); if (rc != GSR_OK) return rc; }
     tm.mark(9);
     if (R > 0) {
@@ -804,6 +811,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
         ca.fill.cov3D = dL_dcov3D; ca.fill.sh = shs ? dL_dsh : nullptr; ca.fill.sh_rest = shs_rest ? dL_dsh_rest : nullptr;
         ca.fill.scales = scales ? dL_dscales : nullptr; ca.fill.rots = scales ? dL_drots : nullptr;
         if (persistent) HIP_TRY(launch_composite_bwd_persistent(ca, pk_grid, s), "composite backward launch");
+        else if (lpt) HIP_TRY(launch_composite_bwd_lpt(ca, s), "composite backward launch");
         else HIP_TRY(launch_composite_bwd(ca, bwd_npx, g_exact_cull.load(), g_wpb.load(), s), "composite backward launch");
         if (debug) HIP_TRY(hipStreamSynchronize(s), "composite backward");
     }

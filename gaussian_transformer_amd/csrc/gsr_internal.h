@@ -304,6 +304,8 @@ struct CompositeArgs {
     int seg_len;                 // entries per segment (multiple of 64); 0: no checkpoints, no units
     int asm_walk;                // 1: the written-out splat walk (composite_fwd.hip::walk_batch_2blocks) where it exists, 0: the C++ walk
     int pair_long_n;             // > 0: composite_fwd_pair_kernel -- half tiles with more list entries than this are walked by two waves, one per block
+    int lpt_span;                // > 0 (and seg_len == 0): every half tile files how far its pixels got (SegView::info) and SEG_SEG = lpt_span, so that
+                                 //    gsr_backward can order the reverse pass's half tiles by length (composite_bwd_lpt_kernel)
 };
 hipError_t launch_composite_fwd(const CompositeArgs &a, int npx, int exact_cull, int waves_per_block, hipStream_t s);
 
@@ -348,6 +350,7 @@ hipError_t launch_composite_bwd(const CompositeBwdArgs &a, int npx, int exact_cu
 hipError_t launch_bound_selftest(uint32_t *words, hipStream_t s);
 // persistent reverse kernel (2 blocks per wave): `grid` waves draw the units the forward pass filed; the ticket counter must hold `grid`
 hipError_t launch_composite_bwd_persistent(const CompositeBwdArgs &a, int grid, hipStream_t s);
+hipError_t launch_composite_bwd_lpt(const CompositeBwdArgs &a, hipStream_t s);      // one wave per half tile, the longest first (lists by plan_units)
 int composite_bwd_persistent_grid(int T, int det, int count_mode, int asm_walk);
 // clears the accumulator rows the reverse pass can add into; with plan_grid > 0 its first GSR_SEG_BANDS workgroups also build the
 // persistent reverse kernel's unit lists from what the forward pass left in `seg` and set the ticket counters for `plan_grid` waves

@@ -218,6 +218,9 @@ int32_t gsr_debug_read_wave_trace(int32_t which, uint32_t *out /*[4 * max_units]
  *        compositing kernel walks a half tile whose list has more entries than this with a workgroup of two waves, one per 8x8 block,
  *        instead of one wave over both blocks: the kernel's time there is its longest list walked alone, and a one-block visit is
  *        fewer instructions.  Same images bit for bit.  Needs fwd_blocks_per_wave = 2 and "asm_walk".  Speed only.
+ *   "bwd_lpt" (default 1): on images of more than 6144 tiles the reverse compositing kernel takes its half tiles in order of decreasing
+ *        length (the forward pass files how far each half tile's pixels got, the accumulator-clearing kernel sorts) instead of tile order:
+ *        the kernel's last waves then have short lists.  Same gradients up to the order of float additions.  Speed only.
  *   "dense_pergauss" (0, 1, 2; default 2 = from 500 000 Gaussians): gsr_backward forks a second stream of the library's own (lowest
  *        priority, one per device, created on first use) on which the zeros of every gradient output are written and the Gaussians
  *        with a gradient are listed and their inputs copied into a compact buffer while the compositing kernel runs; the per-Gaussian

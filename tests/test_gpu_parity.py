@@ -807,3 +807,25 @@ def test_compositing_with_several_waves_per_workgroup(kw):
         for k, v in a["grads"].items():
             if v is not None:
                 assert grad_err(v, b["grads"][k]) <= 2e-4, (wpb, k)
+
+
+def test_reverse_pass_in_order_of_decreasing_length_on_large_images():
+    """Above 6144 tiles the reverse compositing kernel takes its half tiles from per-band lists sorted by how far their pixels got
+    (lengths filed by the forward pass, sorted by the planner that runs with the accumulator clearing): the same units, another
+    order -- gradients equal up to the order of float additions; and a forward pass that filed nothing (option off at forward time)
+    leaves the lists in tile order."""
+    from gaussian_transformer_amd import _lib
+    sc = synth.make_scene(P=200000, width=1920, height=1080, sh_degree=3, s0=0.01, seed=3)
+    S = oracle_scene(sc)
+    assert _lib.get_option("bwd_lpt") == 1
+    a = hip_forward_backward(S, sc.dL_dimage)
+    _lib.set_option("bwd_lpt", 0)
+    try:
+        b = hip_forward_backward(S, sc.dL_dimage)
+    finally:
+        _lib.set_option("bwd_lpt", 1)
+    assert np.array_equal(a["color"], b["color"])
+    for k, v in a["grads"].items():
+        if v is not None:
+            assert np.abs(v).max() > 0 or k == "means2D"
+            assert grad_err(v, b["grads"][k]) <= 2e-4, k
