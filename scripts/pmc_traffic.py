@@ -7,7 +7,7 @@ figure is an upper bound for them.)   usage: pmc_traffic.py <pmc dir> <tag> <out
 import csv, glob, json, os, re, sys, collections
 
 d, tag, out = sys.argv[1], sys.argv[2], sys.argv[3]
-STAGES = [("composite_bwd_walk_kernel", "bwd.composite"), ("composite_bwd_pk_walk_kernel", "bwd.composite"), ("composite_fwd_walk_kernel", "fwd.composite"),
+STAGES = [("composite_bwd_lpt_kernel", "bwd.composite"), ("composite_bwd_walk_kernel", "bwd.composite"), ("composite_bwd_pk_walk_kernel", "bwd.composite"), ("composite_fwd_walk_kernel", "fwd.composite"),
           ("pergauss_bwd_dense_kernel", "bwd.pergauss"), ("gather_visible_kernel", "bwd.second_stream"), ("fill_zero_kernel", "bwd.second_stream"),
           ("composite_bwd_kernel", "bwd.composite"), ("composite_bwd_pk_kernel", "bwd.composite"), ("zero_marked_rows_kernel", "bwd.clear+plan"), ("composite_fwd_kernel", "fwd.composite"),
           ("preprocess_fwd_kernel", "fwd.preprocess"), ("pergauss_bwd_kernel", "bwd.pergauss"),
@@ -31,7 +31,7 @@ for f in sorted(glob.glob(os.path.join(d, f"{tag}_pass*_counter_collection.csv")
         continue
     cname = next(r["Counter_Name"] for r in rows if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"))
     is_fwd = lambda n: "composite_fwd_kernel" in n or "composite_fwd_walk_kernel" in n
-    is_bwd = lambda n: any(k in n for k in ("composite_bwd_kernel", "composite_bwd_walk_kernel", "composite_bwd_pk_kernel", "composite_bwd_pk_walk_kernel"))
+    is_bwd = lambda n: any(k in n for k in ("composite_bwd_kernel", "composite_bwd_lpt_kernel", "composite_bwd_walk_kernel", "composite_bwd_pk_kernel", "composite_bwd_pk_walk_kernel"))
     n_fwd = sum(1 for r in rows if is_fwd(r["Kernel_Name"]) and r["Counter_Name"] == cname)
     n_bwd = sum(1 for r in rows if is_bwd(r["Kernel_Name"]) and r["Counter_Name"] == cname)
     per_kernel = collections.defaultdict(list)
@@ -60,7 +60,7 @@ try:
     for k, v in summ.items():
         if instrumented(k):
             continue
-        for pat, st in (("composite_bwd_walk_kernel", "bwd.composite"), ("composite_bwd_pk_walk_kernel", "bwd.composite"), ("composite_fwd_walk_kernel", "fwd.composite"),
+        for pat, st in (("composite_bwd_lpt_kernel", "bwd.composite"), ("composite_bwd_walk_kernel", "bwd.composite"), ("composite_bwd_pk_walk_kernel", "bwd.composite"), ("composite_fwd_walk_kernel", "fwd.composite"),
                         ("composite_bwd_kernel", "bwd.composite"), ("composite_bwd_pk_kernel", "bwd.composite"), ("composite_fwd_kernel", "fwd.composite")):
             if pat in k and v.get("SQ_INSTS_VALU"):
                 res[st + ".insts"] = {"valu": int(v["SQ_INSTS_VALU"]), "salu": int(v.get("SQ_INSTS_SALU", 0)), "lds": int(v.get("SQ_INSTS_LDS", 0)),
