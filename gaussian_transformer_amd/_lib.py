@@ -52,6 +52,7 @@ SIGNATURES = {
                             _i32,                                     # debug
                             _p, _i32, _p]),                           # shs_rest raw_params dL_dsh_rest
     "gsr_mark_visible": (_i32, [_p, _i32, _p, _p, _p, _p]),
+    "gsr_backward_prefill": (_i32, [_i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),   # P M + gsr_backward's 8 gradient outputs, dL_dsh_rest
     "gsr_composited_mask": (_i32, [_p, _i32, _p, C.c_size_t, _p]),
     "gsr_debug_read_geom": (_i32, [_p, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "gsr_debug_read_binning": (_i32, [_p, C.c_int64, _i32, _i32, _p, _p, _p, _p, _p]),

@@ -35,6 +35,7 @@ static std::atomic<int> g_count_lanes{0};      // 1: instrumented compositing ke
 static std::atomic<int> g_deterministic_bwd{0};   // 1: fixed-order reduction of the reverse pass's partial gradients
 static std::atomic<int> g_seg_len{256};           // entries per segment of the reverse pass's work units (multiple of 64); 0: whole half tiles
 static std::atomic<int> g_dense_pergauss{2};      // per-Gaussian backward on the Gaussians with a gradient only, zero rows filled on a second stream: 0 off, 1 on, 2 = from GSR_DENSE_MIN_P Gaussians
+static std::atomic<int> g_prefill_at{1};           // announced gradient outputs (gsr_backward_prefill): zero-filled 1 = beside the forward compositing kernel, 2 = beside the list-ordering kernel already, 0 = announcements ignored
 static std::atomic<int> g_dense_fork{2};           // dense per-Gaussian stage: 1 = the second stream is forked after the accumulator rows are cleared, 0 = before, 2 = after below GSR_DENSE_FORK_EARLY_P Gaussians
 static std::atomic<int> g_fwd_pair_long{-1};       // forward pass on small images (seg_plan: persistent reverse kernel in use): half tiles whose list exceeds this many entries are walked by two waves, one per block; 0 = off, -1 = GSR_PAIR_LONG_DEFAULT
 static std::atomic<int> g_bwd_lpt{1};             // large images: the reverse pass's half tiles in order of decreasing length (composite_bwd_lpt_kernel); 0 = in tile order
@@ -66,8 +67,11 @@ struct DeviceState {
     CompositeCounters *counters = nullptr;        // [2] device memory: forward, reverse (allocated on first use of count_lanes)
     // gsr_backward's second stream (lowest priority): the zero-fill of the gradient outputs runs there, beside the compositing kernel
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_prefill = nullptr;
     bool side_failed = false;
+    // gsr_backward_prefill: the outputs announced for the backward call that follows the next forward pass (pending), and the ones
+    // that forward pass zero-filled (done; single use, dropped by the next gsr_forward or gsr_backward on the device)
+    struct Prefill { bool pending = false, done = false; int P = 0, M = 0; float *p[9] = {nullptr}; } prefill;
 };
 static DeviceState g_dev[GSR_MAX_DEVICES];
 static DeviceState &dev_state();
@@ -105,7 +109,8 @@ static bool side_stream(DeviceState &ds) {
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (hipStreamCreateWithPriority(&ds.side, hipStreamNonBlocking, least) != hipSuccess ||
         hipEventCreateWithFlags(&ds.ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ds.ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ds.ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ds.ev_prefill, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
         ds.side = nullptr; ds.side_failed = true;
         return false;
@@ -373,6 +378,10 @@ int32_t gsr_set_option(const char *name, int32_t value) {
     if (name && !strcmp(name, "asm_walk")) { g_asm_walk.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "bwd_lpt")) { g_bwd_lpt.store(value ? 1 : 0); return GSR_OK; }
     if (name && !strcmp(name, "fwd_pair_long")) { g_fwd_pair_long.store(value < -1 ? -1 : value); return GSR_OK; }
+    if (name && !strcmp(name, "prefill_at")) {
+        if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARGUMENT, "prefill_at must be 0, 1 or 2");
+        g_prefill_at.store(value); return GSR_OK;
+    }
     if (name && !strcmp(name, "dense_fork")) {
         if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARGUMENT, "dense_fork must be 0, 1 or 2");
         g_dense_fork.store(value); return GSR_OK;
@@ -418,6 +427,7 @@ int32_t gsr_get_option(const char *name, int32_t *value) {
     if (name && value && !strcmp(name, "asm_walk")) { *value = g_asm_walk.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "bwd_lpt")) { *value = g_bwd_lpt.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "fwd_pair_long")) { *value = g_fwd_pair_long.load(); return GSR_OK; }
+    if (name && value && !strcmp(name, "prefill_at")) { *value = g_prefill_at.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "dense_fork")) { *value = g_dense_fork.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "dense_pergauss")) { *value = g_dense_pergauss.load(); return GSR_OK; }
     if (name && value && !strcmp(name, "poll_timeouts")) { *value = dev_state().poll_timeouts.load(); return GSR_OK; }
@@ -476,6 +486,27 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     (void)prefiltered;   // culled Gaussians are always skipped, as with prefiltered=False (the only value the reference passes)
     hipStream_t s = (hipStream_t)stream;
     if (num_rendered) *num_rendered = 0;
+    // Gradient outputs announced for this render's backward call (gsr_backward_prefill): their zeros are written on the device's second
+    // stream beside this pass's last kernels (half of the CUs idle under the list-ordering kernel, most of them in the compositing
+    // kernel's tail) instead of beside the reverse compositing kernel, whose waves leave no slot free until it drains.  Only where
+    // gsr_backward will take the dense per-Gaussian stage (same rule as there), which is what needs the zeros.
+    DeviceState::Prefill pre;
+    bool prefill = false, prefilled = false;
+    {
+        DeviceState &d0 = dev_state();
+        std::lock_guard<std::mutex> lk(d0.mu);
+        if (d0.prefill.done) {       // an earlier render's fill that no gsr_backward took over: ordered before everything this call writes
+            d0.prefill.done = false;
+            if (hipStreamWaitEvent(s, d0.ev_prefill, 0) != hipSuccess) return fail(GSR_ERR_HIP, "prefill join");
+        }
+        if (d0.prefill.pending) {
+            d0.prefill.pending = false;
+            const int dopt = g_dense_pergauss.load();
+            pre = d0.prefill;
+            prefill = g_prefill_at.load() != 0 && P > 0 && pre.P == P && pre.M == M && !debug && (dopt == 1 || (dopt == 2 && P >= GSR_DENSE_MIN_P)) &&
+                      shs && !shs_rest && M == 16 && scales && rotations && pre.p[5] && !pre.p[6] && side_stream(d0);
+        }
+    }
     if (P < 0 || W <= 0 || H <= 0 || !out_color || !bg || !viewmatrix || !projmatrix)
         return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward: bad sizes or missing bg/matrices/out_color");
     if (W > 65535 * GSR_TILE_HOST || H > 65535 * GSR_TILE_HOST) return fail(GSR_ERR_INVALID_ARGUMENT, "image too large");
@@ -505,6 +536,23 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
     if (geom_bytes < g.total_bytes) return fail(GSR_ERR_WORKSPACE, "geom workspace %zu < %zu", geom_bytes, g.total_bytes);
     if (img_bytes < im.total_bytes) return fail(GSR_ERR_WORKSPACE, "image workspace %zu < %zu", img_bytes, im.total_bytes);
     const int gridx = grid_dim(W), gridy = grid_dim(H), T = gridx * gridy;
+
+    auto prefill_now = [&]() -> int32_t {
+        if (!prefill) return GSR_OK;
+        prefill = false;
+        DeviceState &d0 = dev_state();
+        std::lock_guard<std::mutex> lk(d0.mu);
+        PergaussBwdArgs fa{};
+        fa.P = P; fa.M = M; fa.shs = shs;
+        fa.dL_dmeans2D = pre.p[0]; fa.dL_dopacity = pre.p[1]; fa.dL_dcolors = pre.p[2]; fa.dL_dmeans3D = pre.p[3]; fa.dL_dcov3D = pre.p[4];
+        fa.dL_dsh = pre.p[5]; fa.dL_dscales = pre.p[7]; fa.dL_drots = pre.p[8];
+        HIP_TRY(hipEventRecord(d0.ev_fork, s), "prefill fork event");
+        HIP_TRY(hipStreamWaitEvent(d0.side, d0.ev_fork, 0), "prefill fork wait");
+        HIP_TRY(launch_fill_zero(fa, d0.side), "gradient zero-fill launch");
+        HIP_TRY(hipEventRecord(d0.ev_prefill, d0.side), "prefill event");
+        prefilled = true;
+        return GSR_OK;
+    };
 
     StageTimer tm(s, g_profiling.load() != 0);
     tm.mark(0);
@@ -560,6 +608,7 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
             b = carve_binning(bin_ptr, N, 0);
             tm.zero(3); tm.zero(5);
             tm.mark(4);
+            if (g_prefill_at.load() == 2) { const int32_t rc = prefill_now(); if (rc != GSR_OK) return rc; }
             HIP_TRY(launch_super_sort_expand(g, im, b.point_list, P, W, H, h[1], s), "super-tile lists: order + expand");
             tm.mark(7);
             lists_done = true;
@@ -679,10 +728,31 @@ int32_t gsr_forward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int32_
         ca.pair_long_n = sp.small_image && g_fwd_npx.load() == 2 ? (pl < 0 ? GSR_PAIR_LONG_DEFAULT : pl) : 0;
     }
     ca.lpt_span = (!sp.small_image && sp.seg_len == 0 && g_bwd_lpt.load() && g_fwd_npx.load() == 2 && g_bwd_npx.load() == 2 && T <= (1 << 28)) ? GSR_LPT_SPAN : 0;
+    { const int32_t rc = prefill_now(); if (rc != GSR_OK) return rc; }
     HIP_TRY(launch_composite_fwd(ca, g_fwd_npx.load(), pa.exact_cull, g_wpb.load(), s), "composite launch");
     if (debug) HIP_TRY(hipStreamSynchronize(s), "composite");
+    if (prefilled) {        // joined by the gsr_backward that takes the buffers over, or by the next call on the device (no wait here: the
+                            // fill's tail runs on beside the kernels between the two passes)
+        DeviceState &d0 = dev_state();
+        std::lock_guard<std::mutex> lk(d0.mu);
+        d0.prefill = pre; d0.prefill.pending = false; d0.prefill.done = true;
+    }
     tm.mark(-1);
     tm.finish(11);
+    return GSR_OK;
+}
+
+int32_t gsr_backward_prefill(int32_t P, int32_t M, float *dL_dmeans2D, float *dL_dopacity, float *dL_dcolors, float *dL_dmeans3D,
+                             float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drots, float *dL_dsh_rest) {
+    DeviceState &ds = dev_state();
+    std::lock_guard<std::mutex> lk(ds.mu);
+    ds.prefill.pending = false;
+    if (P <= 0) return GSR_OK;               // withdraws an announcement
+    if (M < 0) return fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward_prefill: M < 0");
+    float *const outs[9] = {dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscales, dL_drots};
+    ds.prefill.P = P; ds.prefill.M = M;
+    memcpy(ds.prefill.p, outs, sizeof outs);
+    ds.prefill.pending = true;
     return GSR_OK;
 }
 
@@ -772,6 +842,19 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
         std::lock_guard<std::mutex> lk(ds.mu);
         if (!side_stream(ds)) dense = false;
     }
+    // outputs the matching forward pass has zero-filled already (gsr_backward_prefill): no fill here, and the second stream's order
+    // (that fill, then this call's gathering kernel, then the join event) covers it.  Any other outstanding fill is joined first.
+    bool prefilled = false;
+    {
+        DeviceState &ds = dev_state();
+        std::lock_guard<std::mutex> lk(ds.mu);
+        if (ds.prefill.done) {
+            ds.prefill.done = false;
+            float *const outs[9] = {dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscales, dL_drots};
+            prefilled = dense && ds.prefill.P == P && ds.prefill.M == M && !memcmp(outs, ds.prefill.p, sizeof outs);
+            if (!prefilled) HIP_TRY(hipStreamWaitEvent(s, ds.ev_prefill, 0), "prefill join");
+        }
+    }
     // the fork: after the accumulator rows are cleared, the clearing kernel has the chip to itself (7 us; 18 with the gathering kernel
     // starting beside it) and the second stream's work starts with the compositing kernel -- config 3: 4 us better; at 5 M Gaussians
     // the second stream's work (1.2 GB of zeros, 450 k records) outlasts the compositing kernel's shadow and every microsecond of
@@ -783,7 +866,7 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
         HIP_TRY(hipStreamWaitEvent(ds.side, ds.ev_fork, 0), "fork wait");
         HIP_TRY(hipMemsetAsync(pa.vis_count, 0, 256, ds.side), "visible counter");
         HIP_TRY(launch_gather_visible(pa, ds.side), "gather launch");
-        HIP_TRY(launch_fill_zero(pa, ds.side), "gradient zero-fill launch");
+        if (!prefilled) HIP_TRY(launch_fill_zero(pa, ds.side), "gradient zero-fill launch");
         HIP_TRY(hipEventRecord(ds.ev_join, ds.side), "join event");
         return GSR_OK;
     };

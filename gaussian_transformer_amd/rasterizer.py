@@ -56,6 +56,7 @@ class HipBackend:
     def __init__(self):
         self.lib = _lib.load()
         self._ws_cache = {}
+        self._announced = {}         # device index -> (geom pointer, P, M, gradient tensors) of a forward(announce_backward=True)
         self._bin_hint = {}          # (P, W, H) -> bytes of binning workspace the last forward pass of that shape asked for
 
     def _sizes(self, P, W, H):
@@ -70,8 +71,37 @@ class HipBackend:
             self._ws_cache[key] = v
         return v
 
+    def _gradient_outputs(self, dev, P, M, Mrest, has_sr, has_colors, has_cov, arena):
+        """The tensors gsr_backward writes (include/gsr.h): carved from the gradient arena when one is set."""
+        f32 = dict(dtype=torch.float32, device=dev)
+        off = [0]
+
+        def out(shape):
+            n = 1
+            for d in shape:
+                n *= d
+            if arena is None or n == 0:
+                return torch.empty(shape, **f32)
+            v = arena[off[0]:off[0] + n].view(shape)
+            off[0] += n
+            return v
+        g_means3D = out((P, 3))
+        g_sh = out((P, M, 3)) if M > 0 else torch.empty((0,), **f32)
+        g_sh_rest = out((P, Mrest, 3)) if Mrest > 0 else None
+        g_opacity = out((P, 1))
+        g_scales = out((P, 3)) if has_sr else torch.empty((0,), **f32)
+        g_rots = out((P, 4)) if has_sr else torch.empty((0,), **f32)
+        g_means2D = torch.empty((P, 3), **f32)
+        # gradients of the inputs that were not given are not written at all (36 B per Gaussian less to store)
+        g_colors = torch.empty((P, 3), **f32) if has_colors else None
+        g_cov3D = torch.empty((P, 6), **f32) if has_cov else None
+        return g_means3D, g_means2D, g_sh, g_colors, g_opacity, g_scales, g_rots, g_cov3D, g_sh_rest
+
     def forward(self, rs: GaussianRasterizationSettings, means3D, shs, colors_precomp, opacities, scales, rotations,
-                cov3D_precomp, shs_rest=None, raw_params=False):
+                cov3D_precomp, shs_rest=None, raw_params=False, announce_backward=False):
+        """announce_backward: a backward() call for this render will follow.  Its gradient tensors are created now and announced
+        to the library (gsr_backward_prefill), which writes their zeros beside this forward pass where that pays; backward() picks
+        them up.  Not with a gradient arena (dist.py swaps arenas between the two calls) nor in the fused form."""
         dev = means3D.device
         if dev.type != "cuda":
             raise _lib.GsrError(f"the HIP rasterizer needs tensors on a HIP device, got {dev} (no CPU fallback)")
@@ -111,13 +141,25 @@ class HipBackend:
             n = C.c_int64(0)
             bg = _f32c(rs.bg, "bg", dev); vm = _f32c(rs.viewmatrix, "viewmatrix", dev)
             pm = _f32c(rs.projmatrix, "projmatrix", dev); cp = _f32c(rs.campos, "campos", dev)
+            stale = self._announced.pop(dev.index, None)      # kept allocated until gsr_forward has ordered its fill (include/gsr.h)
+            grads = None
+            if announce_backward and _grad_arena is None and shs_rest is None and P > 0:
+                grads = self._gradient_outputs(dev, P, M, 0, scales.numel() > 0, colors_precomp.numel() > 0, cov3D_precomp.numel() > 0, None)
+                g_means3D, g_means2D, g_sh, g_colors, g_opacity, g_scales, g_rots, g_cov3D, _ = grads
+                _lib.check(self.lib.gsr_backward_prefill(P, M, _ptr(g_means2D), _ptr(g_opacity), _ptr(g_colors), _ptr(g_means3D), _ptr(g_cov3D),
+                                                         _ptr(g_sh), _ptr(g_scales), _ptr(g_rots), None), "gsr_backward_prefill")
             rc = self.lib.gsr_forward(
                 stream, P, int(rs.sh_degree), M, W, H, _ptr(bg), _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
                 _ptr(opacities), _ptr(scales), float(rs.scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
                 _ptr(vm), _ptr(pm), _ptr(cp), float(rs.tanfovx), float(rs.tanfovy), int(bool(rs.prefiltered)),
                 int(bool(rs.debug)), color.data_ptr(), _ptr(radii), geom.data_ptr(), gb, cb, None, img.data_ptr(), ib,
                 C.byref(n), _ptr(shs_rest), int(bool(raw_params)))
+            if rc != 0 and grads is not None:
+                self.lib.gsr_backward_prefill(0, 0, None, None, None, None, None, None, None, None, None)
+            del stale
             _lib.check(rc, "gsr_forward")
+            if grads is not None:
+                self._announced[dev.index] = (geom.data_ptr(), P, M, grads)     # one render per device: the next forward() drops it
             if asked[0]:
                 self._bin_hint[key] = asked[0]
                 if len(self._bin_hint) > 64:
@@ -143,27 +185,12 @@ class HipBackend:
                                       or arena.numel() < arena_floats(P, M + Mrest, has_sr)):
                 raise _lib.GsrError("gradient arena must be a contiguous float32 tensor on the render device with "
                                     f"at least {arena_floats(P, M + Mrest, has_sr)} elements")
-            off = [0]
-
-            def out(shape):
-                n = 1
-                for d in shape:
-                    n *= d
-                if arena is None or n == 0:
-                    return torch.empty(shape, **f32)
-                v = arena[off[0]:off[0] + n].view(shape)
-                off[0] += n
-                return v
-            g_means3D = out((P, 3))
-            g_sh = out((P, M, 3)) if M > 0 else torch.empty((0,), **f32)
-            g_sh_rest = out((P, Mrest, 3)) if Mrest > 0 else None
-            g_opacity = out((P, 1))
-            g_scales = out((P, 3)) if has_sr else torch.empty((0,), **f32)
-            g_rots = out((P, 4)) if has_sr else torch.empty((0,), **f32)
-            g_means2D = torch.empty((P, 3), **f32)
-            # gradients of the inputs that were not given are not written at all (36 B per Gaussian less to store)
-            g_colors = torch.empty((P, 3), **f32) if colors_precomp.numel() else None
-            g_cov3D = torch.empty((P, 6), **f32) if cov3D_precomp.numel() else None
+            ann = self._announced.pop(dev.index, None)
+            if ann is not None and arena is None and ann[:3] == (geom.data_ptr(), P, M) and Mrest == 0:
+                grads = ann[3]                       # created (and, where it pays, zero-filled) by the forward pass
+            else:
+                grads = self._gradient_outputs(dev, P, M, Mrest, has_sr, colors_precomp.numel() > 0, cov3D_precomp.numel() > 0, arena)
+            g_means3D, g_means2D, g_sh, g_colors, g_opacity, g_scales, g_rots, g_cov3D, g_sh_rest = grads
             bg = _f32c(rs.bg, "bg", dev); vm = _f32c(rs.viewmatrix, "viewmatrix", dev)
             pm = _f32c(rs.projmatrix, "projmatrix", dev); cp = _f32c(rs.campos, "campos", dev)
             dL = _f32c(dL_dpix, "grad of rendered image", dev)
@@ -175,6 +202,7 @@ class HipBackend:
                 bwd_ws.numel(), _ptr(g_means2D), _ptr(g_opacity), _ptr(g_colors), _ptr(g_means3D), _ptr(g_cov3D),
                 _ptr(g_sh), _ptr(g_scales), _ptr(g_rots), int(bool(rs.debug)), _ptr(shs_rest), int(bool(raw_params)),
                 _ptr(g_sh_rest))
+            del ann
             _lib.check(rc, "gsr_backward")
         if shs_rest is not None:
             return g_means3D, g_means2D, g_sh, g_colors, g_opacity, g_scales, g_rots, g_cov3D, g_sh_rest
@@ -300,7 +328,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         means3D_c, sh_c, colors_c, opac_c, scales_c, rots_c, cov_c = args
         try:
             num_rendered, color, radii, geom, binning, img = be.forward(
-                raster_settings, means3D_c, sh_c, colors_c, opac_c, scales_c, rots_c, cov_c)
+                raster_settings, means3D_c, sh_c, colors_c, opac_c, scales_c, rots_c, cov_c,
+                **({"announce_backward": True} if any(ctx.needs_input_grad) and hasattr(be, "_announced") else {}))
         except Exception:
             if raster_settings.debug:
                 _dump("snapshot_fw.dump", *args, raster_settings._asdict())

@@ -125,6 +125,19 @@ int32_t gsr_backward(gsr_stream_t stream, int32_t P, int32_t D, int32_t M, int64
                       * w.r.t. the raw (pre-activation) parameters. */
                      const float *shs_rest, int32_t raw_params, float *dL_dsh_rest);
 
+/* Announces the gradient outputs of the gsr_backward call that will follow the NEXT gsr_forward on the current device (same P, M;
+ * pointers in gsr_backward's order, NULL where that call will pass NULL).  That gsr_forward then writes their zeros on the library's
+ * second stream beside its own last kernels -- where CUs idle --, and the gsr_backward that names exactly these pointers skips its
+ * own zero-fill.  The fill is ordered before that gsr_backward's writes, and before everything the next gsr_forward or gsr_backward
+ * call on the device enqueues, whichever comes first; until one of them has been called the caller keeps the buffers allocated and
+ * does not touch them (the fill may still be running when gsr_forward returns).  Purely optional and purely a matter of time: without it, with other pointers in
+ * gsr_backward, with a second gsr_forward before that gsr_backward, or where gsr_backward would not zero-fill on the second stream
+ * in the first place (see "dense_pergauss"), gsr_backward fills by itself as before.  An announcement is used by one gsr_forward
+ * only; P <= 0 withdraws it.  Host-side state, no device work.  Extension: the reference allocates its gradients with torch::zeros
+ * inside RasterizeGaussiansBackwardCUDA, i.e. pays the same fill on the critical path. */
+int32_t gsr_backward_prefill(int32_t P, int32_t M, float *dL_dmeans2D, float *dL_dopacity, float *dL_dcolors, float *dL_dmeans3D,
+                             float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drots, float *dL_dsh_rest);
+
 /* present[i] = 1 iff Gaussian i passes the near-plane test (view z > 0.2). */
 int32_t gsr_mark_visible(gsr_stream_t stream, int32_t P, const float *means3D, const float *viewmatrix,
                          const float *projmatrix, uint8_t *present /*[P]*/);
@@ -227,6 +240,8 @@ int32_t gsr_debug_read_wave_trace(int32_t which, uint32_t *out /*[4 * max_units]
  *        kernel then runs on those only.  Applies to shs with M = 16 and scales + rotations (other layouts: the streaming kernel).
  *        The caller's stream sees one event record and one event wait; the join is enqueued before gsr_backward returns.  Same
  *        gradients (bit for bit under "deterministic_bwd").  Speed only.
+ *   "prefill_at" (0, 1, 2; default 1): where a gsr_forward zero-fills gradient outputs announced through gsr_backward_prefill --
+ *   1 beside its compositing kernel, 2 beside the list-ordering kernel already, 0 announcements are ignored.
  *   "dense_fork" (0, 1, 2; default 2): where that fork happens -- 1 after the accumulator rows are cleared, 0 before, 2 = after below
  *        2 000 000 Gaussians.
  *   Options that change what the forward pass leaves for the reverse pass ("persistent_bwd", "segment_entries", the blocks-per-wave

@@ -829,3 +829,78 @@ def test_reverse_pass_in_order_of_decreasing_length_on_large_images():
         if v is not None:
             assert np.abs(v).max() > 0 or k == "means2D"
             assert grad_err(v, b["grads"][k]) <= 2e-4, k
+
+
+@pytest.mark.parametrize("at", [1, 2, 0])
+def test_announced_gradient_outputs_are_zero_filled_by_the_forward_pass(at):
+    """gsr_backward_prefill (include/gsr.h): gradient outputs announced before a forward pass are zero-filled by that pass on the
+    library's second stream (`prefill_at` 1: beside the compositing kernel, 2: beside the list-ordering kernel; 0: announcements are
+    ignored) and the backward call that names them skips its own fill.  Buffers that held NaNs must hold exact zeros after the forward
+    call (or still NaNs with 0), and -- with the deterministic reverse pass -- the gradients must equal, bit for bit, those of a
+    backward call that was never announced; so must those of a render whose announcement was overtaken by another forward pass."""
+    import torch
+    from gaussian_transformer_amd import _lib
+    from gaussian_transformer_amd.rasterizer import GaussianRasterizationSettings, get_backend
+    be = get_backend()
+    sc = synth.make_scene(P=300000, width=800, height=800, sh_degree=2, max_sh_degree=3, s0=0.01, seed=32)
+    cam, P = sc.camera, sc.P
+    t = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=np.float32), device="cuda")
+    rs = GaussianRasterizationSettings(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy, t(sc.bg), 1.0, t(cam.world_view_transform),
+                                       t(cam.full_proj_transform), sc.sh_degree, t(cam.camera_center), False, False)
+    e = torch.empty(0, device="cuda")
+    a = (t(sc.means3D), t(sc.shs), e, t(sc.opacities.reshape(P, 1)), t(sc.scales), t(sc.rotations), e)
+    dL = t(sc.dL_dimage)
+    M = int(a[1].shape[1])
+    dev = a[0].device
+    names = ("means3D", "means2D", "sh", "colors", "opacity", "scales", "rots", "cov3D")
+
+    def backward(f):
+        n, color, radii, geom, binning, img = f
+        g = be.backward(rs, n, dL, a[0], radii, a[1], a[2], a[4], a[5], a[6], geom, binning, img)
+        return {k: (None if v is None else v.cpu().numpy()) for k, v in zip(names, g)}
+
+    def announce():
+        grads = be._gradient_outputs(dev, P, M, 0, True, False, False, None)
+        for g in grads:
+            if g is not None:
+                g.fill_(float("nan"))
+        g_means3D, g_means2D, g_sh, g_colors, g_opacity, g_scales, g_rots, g_cov3D, _ = grads
+        p = lambda x: None if x is None or x.numel() == 0 else x.data_ptr()
+        _lib.check(be.lib.gsr_backward_prefill(P, M, p(g_means2D), p(g_opacity), p(g_colors), p(g_means3D), p(g_cov3D), p(g_sh), p(g_scales),
+                                               p(g_rots), None), "gsr_backward_prefill")
+        return grads
+
+    _lib.set_option("deterministic_bwd", 1); _lib.set_option("dense_pergauss", 1); _lib.set_option("prefill_at", at)
+    try:
+        ref = backward(be.forward(rs, *a))                         # never announced
+        grads = announce()
+        f = be.forward(rs, *a)
+        torch.cuda.synchronize()
+        for g in grads:
+            if g is not None and g.numel():
+                assert bool(torch.isnan(g).all()) if at == 0 else bool((g == 0).all())
+        be._announced[dev.index] = (f[3].data_ptr(), P, M, grads)     # what forward(announce_backward=True) leaves behind
+        got = backward(f)
+        # an announcement overtaken by another forward pass: the first render's backward call fills by itself
+        grads1 = announce()
+        f1 = be.forward(rs, *a)
+        grads2 = announce()
+        f2 = be.forward(rs, *a)
+        for g in grads1:
+            if g is not None:
+                g.fill_(float("nan"))
+        be._announced[dev.index] = (f1[3].data_ptr(), P, M, grads1)
+        late = backward(f1)
+        del f2, grads2
+    finally:
+        _lib.set_option("deterministic_bwd", 0); _lib.set_option("dense_pergauss", 2); _lib.set_option("prefill_at", 1)
+        be._announced.clear()
+    some = False
+    for k, v in ref.items():
+        if v is None:
+            assert got[k] is None and late[k] is None
+            continue
+        assert np.array_equal(v, got[k]), (k, "announced")
+        assert np.array_equal(v, late[k]), (k, "overtaken")
+        some = some or np.abs(v).max() > 0
+    assert some
