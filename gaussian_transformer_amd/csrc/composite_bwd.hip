@@ -648,7 +648,9 @@ __global__ __launch_bounds__(64, 8) void composite_bwd_lpt_kernel(CompositeBwdAr
     const int lane = threadIdx.x;
     const uint32_t band = blockIdx.x & (GSR_SEG_BANDS - 1), idx = blockIdx.x / GSR_SEG_BANDS;
     if (idx >= a.seg.hdr[SEG_BCOUNT + band]) return;             // workgroup-uniform
+    if (!GSR_IDX_OK(idx, a.seg.list_cap, a.seg.hdr + GSR_DBG_SEG_WORD, GSR_BOUND_UNIT_TICKET)) return;
     uint4 u = a.seg.bq[seg_list_base(a.seg, (int)band) + idx];
+    if (!GSR_IDX_OK(u.x, a.seg.units, a.seg.hdr + GSR_DBG_SEG_WORD, GSR_BOUND_UNIT_LIST)) return;
     u.x = __builtin_amdgcn_readfirstlane(u.x); u.y = __builtin_amdgcn_readfirstlane(u.y);
     u.z = __builtin_amdgcn_readfirstlane(u.z); u.w = __builtin_amdgcn_readfirstlane(u.w);
     BwdTally tl;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Renders a set of scenes (random ones over the list builders' regimes, BASELINE configs 2 and 4, long unsaturated lists with the
+"""Renders a set of scenes (random ones over the list builders' regimes, BASELINE configs 2, 3 and 4, a 2560 x 1440 image, long unsaturated lists with the
 segmented reverse pass) forward + backward and reads the capacity-assert words of the library after every one.
 
     GSR_LIB_PATH=gaussian_transformer_amd/libgsr_hip_dbg.so python scripts/debug_bounds_run.py [--scenes 40]
@@ -64,6 +64,9 @@ def main():
     run(synth.make_scene(P=20000, width=32, height=32, sh_degree=0, s0=0.8, seed=4), "overfull bin 32x32 (falls back)")
     run(synth.make_config("cfg2_table_300k_800"), "cfg2")
     run(synth.make_config("cfg4_tiramisu_303k_1600x900"), "cfg4")
+    # a large image with many Gaussians: the reverse pass in order of length, the dense per-Gaussian stage, both assembly walks
+    run(synth.make_config("cfg3_synth_1M_1080p"), "cfg3")
+    run(synth.make_scene(P=200000, width=2560, height=1440, sh_degree=3, s0=0.004, seed=12), "large image 2560x1440")
     # long unsaturated lists: checkpoints, pool exhaustion, overlong remainders, every unit class
     for seg in (64, 256):
         _lib.set_option("persistent_bwd", 1); _lib.set_option("segment_entries", seg)
