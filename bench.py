@@ -165,13 +165,13 @@ def main():
 
     def render_backward(b, arena):
         means2D = means2D_placeholder
-        color, radii = GaussianRasterizer(raster_settings=settings[b])(means3D=means3D, means2D=means2D, shs=shs, opacities=opac, scales=scales, rotations=rots)
-        mask = composited_mask(color) if (ex_sparse and world > 1) else None
         if arena is None:
+            color, radii = GaussianRasterizer(raster_settings=settings[b])(means3D=means3D, means2D=means2D, shs=shs, opacities=opac, scales=scales, rotations=rots)
+            return color, torch.autograd.grad(color, params, grad_outputs=dL), None
+        with gradient_arena(arena):        # around the forward call too: the arena's slices are zero-filled beside the forward pass
+            color, radii = GaussianRasterizer(raster_settings=settings[b])(means3D=means3D, means2D=means2D, shs=shs, opacities=opac, scales=scales, rotations=rots)
+            mask = composited_mask(color) if (ex_sparse and world > 1) else None
             grads = torch.autograd.grad(color, params, grad_outputs=dL)
-        else:
-            with gradient_arena(arena):
-                grads = torch.autograd.grad(color, params, grad_outputs=dL)
         return color, grads, mask
 
     def step():

@@ -101,7 +101,8 @@ class HipBackend:
                 cov3D_precomp, shs_rest=None, raw_params=False, announce_backward=False):
         """announce_backward: a backward() call for this render will follow.  Its gradient tensors are created now and announced
         to the library (gsr_backward_prefill), which writes their zeros beside this forward pass where that pays; backward() picks
-        them up.  Not with a gradient arena (dist.py swaps arenas between the two calls) nor in the fused form."""
+        them up.  With a gradient arena they are its slices if the arena is set around this call as well as around backward() (the
+        same one: anything else makes backward() carve and fill as before).  Not in the fused form."""
         dev = means3D.device
         if dev.type != "cuda":
             raise _lib.GsrError(f"the HIP rasterizer needs tensors on a HIP device, got {dev} (no CPU fallback)")
@@ -143,8 +144,12 @@ class HipBackend:
             pm = _f32c(rs.projmatrix, "projmatrix", dev); cp = _f32c(rs.campos, "campos", dev)
             stale = self._announced.pop(dev.index, None)      # kept allocated until gsr_forward has ordered its fill (include/gsr.h)
             grads = None
-            if announce_backward and _grad_arena is None and shs_rest is None and P > 0:
-                grads = self._gradient_outputs(dev, P, M, 0, scales.numel() > 0, colors_precomp.numel() > 0, cov3D_precomp.numel() > 0, None)
+            arena = _grad_arena            # set around the forward call too: the announced tensors are its slices (and get zeroed now)
+            if arena is not None and (arena.device != dev or arena.dtype != torch.float32 or not arena.is_contiguous()
+                                      or arena.numel() < arena_floats(P, M, scales.numel() > 0)):
+                announce_backward = False  # backward() raises the error
+            if announce_backward and shs_rest is None and P > 0:
+                grads = self._gradient_outputs(dev, P, M, 0, scales.numel() > 0, colors_precomp.numel() > 0, cov3D_precomp.numel() > 0, arena)
                 g_means3D, g_means2D, g_sh, g_colors, g_opacity, g_scales, g_rots, g_cov3D, _ = grads
                 _lib.check(self.lib.gsr_backward_prefill(P, M, _ptr(g_means2D), _ptr(g_opacity), _ptr(g_colors), _ptr(g_means3D), _ptr(g_cov3D),
                                                          _ptr(g_sh), _ptr(g_scales), _ptr(g_rots), None), "gsr_backward_prefill")
@@ -159,7 +164,8 @@ class HipBackend:
             del stale
             _lib.check(rc, "gsr_forward")
             if grads is not None:
-                self._announced[dev.index] = (geom.data_ptr(), P, M, grads)     # one render per device: the next forward() drops it
+                # one render per device: the next forward() drops it
+                self._announced[dev.index] = (geom.data_ptr(), P, M, grads, None if arena is None else (arena.data_ptr(), arena.numel()))
             if asked[0]:
                 self._bin_hint[key] = asked[0]
                 if len(self._bin_hint) > 64:
@@ -186,7 +192,8 @@ class HipBackend:
                 raise _lib.GsrError("gradient arena must be a contiguous float32 tensor on the render device with "
                                     f"at least {arena_floats(P, M + Mrest, has_sr)} elements")
             ann = self._announced.pop(dev.index, None)
-            if ann is not None and arena is None and ann[:3] == (geom.data_ptr(), P, M) and Mrest == 0:
+            if ann is not None and ann[:3] == (geom.data_ptr(), P, M) and Mrest == 0 and \
+                    ann[4] == (None if arena is None else (arena.data_ptr(), arena.numel())):
                 grads = ann[3]                       # created (and, where it pays, zero-filled) by the forward pass
             else:
                 grads = self._gradient_outputs(dev, P, M, Mrest, has_sr, colors_precomp.numel() > 0, cov3D_precomp.numel() > 0, arena)
@@ -249,7 +256,8 @@ class gradient_arena:
     """Context manager: while active, gsr_backward writes dL/d{means3D, shs, opacities, scales, rotations}
     straight into consecutive slices of `flat` (59 floats per Gaussian at M = 16, in that order), so a
     data-parallel step can all-reduce `flat` without a packing copy.  The returned gradient tensors are
-    views of `flat`."""
+    views of `flat`.  Entered around the forward call as well, it lets the library zero those slices beside the forward pass already
+    (gsr_backward_prefill): `flat` then belongs to that render from its forward call on."""
 
     def __init__(self, flat: torch.Tensor):
         self.flat = flat

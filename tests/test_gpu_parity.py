@@ -596,6 +596,51 @@ def test_gradient_arena_matches_separate_buffers():
     assert off == flat.numel()
 
 
+def test_gradient_arena_around_forward_and_backward_is_zero_filled_by_the_forward_pass():
+    """An arena entered around the forward call too: its slices are announced (gsr_backward_prefill) and -- with the dense per-Gaussian
+    stage -- zero-filled beside the forward pass; the gradients must be the same views with the same values (deterministic reverse pass:
+    bit for bit) as with the arena around backward only, whatever the arena held before; a different arena at backward time makes
+    the backward call fill by itself."""
+    from gaussian_transformer_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
+    from gaussian_transformer_amd.rasterizer import arena_floats, gradient_arena
+    sc = synth.make_scene(P=120000, width=640, height=400, sh_degree=3, s0=0.01, seed=43)
+    cam, P = sc.camera, sc.P
+    t = lambda a, g=False: torch.tensor(np.asarray(a, dtype=np.float32), device="cuda").requires_grad_(g)
+    inp = dict(means3D=t(sc.means3D, True), shs=t(sc.shs, True), opacities=t(sc.opacities.reshape(P, 1), True), scales=t(sc.scales, True),
+               rotations=t(sc.rotations, True))
+    rs = GaussianRasterizationSettings(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy, t(sc.bg), 1.0, t(cam.world_view_transform),
+                                       t(cam.full_proj_transform), 3, t(cam.camera_center), False, False)
+    dL = t(sc.dL_dimage)
+    params = list(inp.values())
+    m2 = lambda: torch.zeros(P, 3, device="cuda", requires_grad=True)
+    nan = lambda: torch.full((arena_floats(P, 16),), float("nan"), device="cuda")
+    _lib.set_option("deterministic_bwd", 1); _lib.set_option("dense_pergauss", 1)
+    try:
+        a_ref = nan()
+        c, _ = GaussianRasterizer(raster_settings=rs)(means2D=m2(), **inp)
+        with gradient_arena(a_ref):
+            g_ref = [g.clone() for g in torch.autograd.grad(c, params, grad_outputs=dL)]
+        a_both = nan()
+        with gradient_arena(a_both):
+            c, _ = GaussianRasterizer(raster_settings=rs)(means2D=m2(), **inp)
+            torch.cuda.synchronize()
+            assert bool((a_both == 0).all())                       # zeroed by the forward call
+            g_both = torch.autograd.grad(c, params, grad_outputs=dL)
+        a_fwd, a_bwd = nan(), nan()
+        with gradient_arena(a_fwd):
+            c, _ = GaussianRasterizer(raster_settings=rs)(means2D=m2(), **inp)
+        with gradient_arena(a_bwd):
+            g_swapped = torch.autograd.grad(c, params, grad_outputs=dL)
+    finally:
+        _lib.set_option("deterministic_bwd", 0); _lib.set_option("dense_pergauss", 2)
+    off = 0
+    for r, b, w in zip(g_ref, g_both, g_swapped):
+        assert b.data_ptr() == a_both.data_ptr() + 4 * off and w.data_ptr() == a_bwd.data_ptr() + 4 * off
+        assert torch.equal(r, b) and torch.equal(r, w)
+        off += r.numel()
+    assert off == a_both.numel() and float(g_ref[0].abs().max()) > 0
+
+
 @pytest.mark.parametrize("deg,max_deg", [(3, 3), (1, 3), (0, 1)])
 def test_fused_raw_parameter_path_matches_activation_graph(deg, max_deg):
     """render_fused (raw parameters, activations and the SH cat inside the kernels) against
@@ -879,7 +924,7 @@ def test_announced_gradient_outputs_are_zero_filled_by_the_forward_pass(at):
         for g in grads:
             if g is not None and g.numel():
                 assert bool(torch.isnan(g).all()) if at == 0 else bool((g == 0).all())
-        be._announced[dev.index] = (f[3].data_ptr(), P, M, grads)     # what forward(announce_backward=True) leaves behind
+        be._announced[dev.index] = (f[3].data_ptr(), P, M, grads, None)     # what forward(announce_backward=True) leaves behind
         got = backward(f)
         # an announcement overtaken by another forward pass: the first render's backward call fills by itself
         grads1 = announce()
@@ -889,7 +934,7 @@ def test_announced_gradient_outputs_are_zero_filled_by_the_forward_pass(at):
         for g in grads1:
             if g is not None:
                 g.fill_(float("nan"))
-        be._announced[dev.index] = (f1[3].data_ptr(), P, M, grads1)
+        be._announced[dev.index] = (f1[3].data_ptr(), P, M, grads1, None)
         late = backward(f1)
         del f2, grads2
     finally:
