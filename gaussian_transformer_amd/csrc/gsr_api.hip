@@ -254,7 +254,9 @@ static SegPlan seg_plan(int W, int H) {
     const bool small = T <= GSR_PERSISTENT_MAX_TILES;
     p.persistent_bwd = (pk == 1 || (pk == 2 && small)) && g_bwd_npx.load() == 2 && T <= (1 << 28);
     const bool fwd_seg = (pk == 1 || (pk == 2 && small)) && g_fwd_npx.load() == 2 && T <= (1 << 28);
-    p.seg_len = fwd_seg ? g_seg_len.load() : 0;
+    // not under deterministic_bwd: which half tiles get checkpoints once the pool runs out is a race between the forward waves, and a
+    // segment that starts from a stored transmittance differs in the last bits from the same entries reached by dividing back
+    p.seg_len = fwd_seg && !g_deterministic_bwd.load() ? g_seg_len.load() : 0;
     p.small_image = small;
     return p;
 }

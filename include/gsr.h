@@ -249,7 +249,8 @@ int32_t gsr_debug_read_wave_trace(int32_t which, uint32_t *out /*[4 * max_units]
  *   "deterministic_bwd" (default 0): the reverse compositing pass stores the partial gradients of every (wave, pair)
  *        into a slot of its own and a second kernel adds each Gaussian's slots in a fixed order, instead of float
  *        atomics whose order differs from run to run: bitwise reproducible gradients (race detection).
- *        Needs the larger scratch of gsr_backward_workspace_bytes; slower (debug mode).
+ *        Needs the larger scratch of gsr_backward_workspace_bytes; slower (debug mode).  While it is on the forward pass takes no
+ *        checkpoints ("segment_entries" reads as 0): which half tiles get one when the pool runs out is a race.
  * Adaptive state (which depth-bucket map a device uses after it met depth outliers, "depth_log_map") is kept per
  * DEVICE, not per process; gsr_set_option("depth_log_map", v) sets it for the current device. */
 int32_t gsr_set_option(const char *name, int32_t value);

@@ -87,3 +87,18 @@ def test_fullsize_linearity_and_permutation_at_1e_4(name, deterministic):
     gp = _grads(inp, rs, dL, perm=perm)                      # gradients come back in the leaves' (unpermuted) order
     for k, x, y in zip(KEYS, ga, gp):
         assert grad_err(y, x) < 1e-4, k                      # up to splats with bit-identical depth (ordered by index)
+
+
+def test_long_lists_on_a_small_image_are_reproducible_too(deterministic):
+    """200 k Gaussians over 24 tiles: lists far longer than the forward pass's checkpoint pool covers.  Which half tiles get
+    checkpoints then is a race between forward waves, and a reverse segment that starts from a stored transmittance differs in the
+    last bits from the same entries reached by dividing back -- so the deterministic mode renders without checkpoints (gsr_api.hip
+    seg_plan).  Five runs, one result."""
+    sc = synth.make_scene(P=200000, width=36, height=127, sh_degree=0, max_sh_degree=3, s0=0.05, seed=1, zmin=1.0, zmax=10.0)
+    inp, rs = _setup(sc)
+    dL = torch.tensor(sc.dL_dimage, device="cuda")
+    runs = [_grads(inp, rs, dL) for _ in range(5)]
+    for r in runs[1:]:
+        for a, b in zip(runs[0], r):
+            assert np.array_equal(a, b)
+    assert np.abs(runs[0][0]).max() > 0
