@@ -20,7 +20,7 @@ dev = torch.device("cuda", 0)
 rng = np.random.default_rng(0)
 t0 = time.time(); n = 0; peak = 0; noisy = []; bitwise = 0
 while time.time() - t0 < a.seconds:
-    P = int(rng.choice([1, 50, 1000, 5000, 40000, 200000])); W = int(rng.integers(16, 1500)); H = int(rng.integers(16, 900))
+    P = int(rng.choice([1, 50, 1000, 5000, 40000, 200000] + ([600000] if a.second_stream else []))); W = int(rng.integers(16, 1500)); H = int(rng.integers(16, 900))
     sc = synth.make_scene(P=P, width=W, height=H, sh_degree=int(rng.integers(0, 4)), s0=float(10 ** rng.uniform(-2.5, -0.5)),
                           seed=int(rng.integers(1 << 30)), zmin=float(rng.choice([0.05, 1.0, 3.0])), zmax=float(rng.choice([3.0, 10.0, 200.0])),
                           **({"max_sh_degree": 3} if a.second_stream else {}))
