@@ -210,11 +210,21 @@ def main():
         torch.cuda.synchronize()
 
     def timed(k):
-        sync(); t1 = time.perf_counter()
-        for _ in range(k):
-            step()
-        sync()
-        dt_ = time.perf_counter() - t1
+        # as timeit does: no cyclic-garbage collection of the interpreter inside the timed region (a full collection over the scene's
+        # host-side objects is milliseconds -- a quarter of a 20-step region; two such one-off stalls were seen in ~40 runs of round 3)
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            sync(); t1 = time.perf_counter()
+            for _ in range(k):
+                step()
+            sync()
+            dt_ = time.perf_counter() - t1
+        finally:
+            if gc_was_on:
+                gc.enable()
         if world > 1:
             tt_ = torch.tensor([dt_], dtype=torch.float64, device=dev)
             dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
